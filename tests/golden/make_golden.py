@@ -1,0 +1,385 @@
+"""Generate tests/golden/*.npz by running the REAL reference (read-only at /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box);
+the .npz files it writes are plain numbers: explicit small inputs (noise, indices,
+batches) and the reference's outputs.  Large inputs (network weights) are NOT
+stored: tests regenerate them from `gen_inputs.py` and verify the stored checksum.
+
+Harness-side shims (no reference file is modified):
+  * `algo.mb_utils.logger` is pre-seeded with a stub (its `tensorboard` import is the
+    only thing that blocks `algo.dynamics.mobody_dynamics`).
+  * `torch.normal` / `np.random.choice` are wrapped while `step()` runs so the unit
+    noise eps[E,B,S] and the elite ids [B] are explicit fixture inputs
+    (`torch.normal(0,std)` is replaced by `eps*std`).
+
+Usage:  python tests/golden/make_golden.py        (writes next to this file)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference")
+_stub = types.ModuleType("algo.mb_utils.logger")
+_stub.Logger = object
+sys.modules["algo.mb_utils.logger"] = _stub
+
+import gen_inputs as gi  # noqa: E402
+from algo.dynamics.mobody_module import MOBODYModule, EnsembleLinear  # noqa: E402
+from algo.dynamics.mobody_dynamics import MOBODYEnsembleDynamics  # noqa: E402
+from algo.offline_offline.mobody import MOBODY  # noqa: E402
+from algo.mb_utils.terminal_funs import get_termination_fn  # noqa: E402
+from algo import utils as ref_utils  # noqa: E402
+
+torch.set_num_threads(1)
+DYN_CFG = dict(mopo=0, latent_reward=0, encoder_loss_coef=1, domain_loss_coef=0.0, cycle_loss_coef=0.3)
+
+
+def sub(x):
+    """Fixture thinning for big tensors (tests apply the same rule to their side)."""
+    x = np.asarray(x)
+    f = x.reshape(-1)
+    return f[::13].copy() if f.size > 4096 else f.copy()
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print("wrote", name, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+class RngTap:
+    """Explicit noise / elite ids for MOBODYEnsembleDynamics.step (mobody_dynamics.py:220,224)."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.eps, self.idx = [], []
+
+    def __enter__(self):
+        self._n, self._c = torch.normal, np.random.choice
+
+        def normal(mean=None, std=None, **kw):
+            e = torch.from_numpy(self.rng.standard_normal(tuple(std.shape)).astype(np.float32))
+            self.eps.append(e.numpy().copy())
+            return mean + e * std
+
+        def choice(a, size=None, **kw):
+            i = self._c(a, size=size, **kw)
+            self.idx.append(np.asarray(i).copy())
+            return i
+
+        torch.normal, np.random.choice = normal, choice
+        return self
+
+    def __exit__(self, *a):
+        torch.normal, np.random.choice = self._n, self._c
+
+
+def load_dyn(S, A, seed, alive_dim, alive_val):
+    p = gi.dyn_params(seed, S, A)
+    p["transition3.bias"][:, 0, alive_dim] += np.float32(alive_val)
+    m = MOBODYModule(S, A, 256, 7, 5, device="cpu", config=dict(DYN_CFG))
+    sd = m.state_dict()
+    for k, v in p.items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = torch.from_numpy(v)
+    m.load_state_dict(sd)
+    return m, p
+
+
+# --------------------------------------------------------------------------- G1
+def g1():
+    rng = np.random.default_rng(11)
+    lin = EnsembleLinear(17, 32, 7)
+    W = gi._w(rng, (7, 17, 32), 0.2); b = gi._w(rng, (7, 1, 32), 0.1)
+    lin.weight.data.copy_(torch.from_numpy(W)); lin.bias.data.copy_(torch.from_numpy(b))
+    x2 = rng.standard_normal((8, 17)).astype(np.float32)
+    x3 = rng.standard_normal((7, 8, 17)).astype(np.float32)
+    with torch.no_grad():
+        y2 = lin(torch.from_numpy(x2)).numpy(); y3 = lin(torch.from_numpy(x3)).numpy()
+    save("g1_ensemble_linear", W=W, b=b, x2=x2, x3=x3, y2=y2, y3=y3)
+
+
+# ----------------------------------------------------------------------- G2-G4
+SHAPES = [  # (tag, S, A, B, task, alive_dim, alive_val, seed)
+    ("walker", 17, 6, 48, "walker2d-medium-v2", 0, 0.85, 101),
+    ("ant", 111, 8, 16, "ant-medium-v2", 0, 0.25, 102),
+    ("pen", 45, 24, 16, "pen-human-v1", 26, 0.075, 103),
+]
+
+
+def g234():
+    for tag, S, A, B, task, ad, av, seed in SHAPES:
+        m, p = load_dyn(S, A, seed, ad, av)
+        rng = np.random.default_rng(seed + 1000)
+        obs = gi.walker_like_obs(rng, B, S); act = rng.uniform(-1, 1, (B, A)).astype(np.float32)
+        nxt = gi.walker_like_obs(rng, B, S)
+        m.inference()
+        with torch.no_grad():
+            mt, zmu, zlv = m.forward_trg(torch.from_numpy(obs), torch.from_numpy(act))
+            ms, _, _ = m.forward_src(torch.from_numpy(obs), torch.from_numpy(act))
+            rmu, rlv = m.encode_reward(torch.from_numpy(obs), torch.from_numpy(act), torch.from_numpy(nxt))
+        out = dict(S=S, A=A, seed=seed, alive_dim=ad, alive_val=av, task=task, wsum=gi.checksum(p), obs=obs, act=act,
+                   nxt=nxt, mean_trg=mt.numpy(), mean_src=ms.numpy(), zs_mu=zmu.numpy(), zs_logvar=zlv.numpy(),
+                   r_mu=rmu.numpy(), r_logvar=rlv.numpy())
+        dyn = MOBODYEnsembleDynamics(dict(DYN_CFG), m, None, None, get_termination_fn(task), penalty_coef=0.1)
+        for up in (True, False):
+            for ut in (True, False):
+                np.random.seed(seed)
+                with RngTap(seed + 7) as tap:
+                    no, rw, term, info = dyn.step(torch.from_numpy(obs), torch.from_numpy(act), up, ut)
+                k = f"step_p{int(up)}_t{int(ut)}_"
+                out.update({k + "eps": tap.eps[0], k + "idx": tap.idx[0], k + "next_obs": no.numpy(),
+                            k + "reward": rw.numpy(), k + "terminal": term, k + "penalty": info["penalty"].numpy(),
+                            k + "raw_reward": info["raw_reward"].numpy(), k + "samples": info["samples"].numpy()})
+        print(tag, "terminated rows:", int(out["step_p1_t1_terminal"].sum()), "/", B)
+        save(f"g234_dynamics_{tag}", **out)
+
+
+# --------------------------------------------------------------------------- G5
+def g5():
+    rng = np.random.default_rng(5)
+    out = {}
+    tasks = ["halfcheetah-medium-v2", "hopper-medium-v2", "walker2d-medium-v2", "ant-medium-v2",
+             "halfcheetahvel-x", "antangle-x", "humanoid-x", "pen-human-v1", "door-human-v1", "pendulum-x"]
+    special = np.array([0.8, 2.0, 1.0, -1.0, 100.0, -100.0, 0.7, 0.2, -0.2, 0.075, 99.99, -99.99, 0.0, 1.5, 1.25,
+                        np.nan, np.inf, -np.inf, 0.8000001, 1.9999999, 0.2000001, 0.6999999], np.float32)
+    for t in tasks:
+        S = 45 if "pen" in t or "door" in t else 17
+        n = gi.walker_like_obs(rng, 96, S)
+        # sprinkle boundary values on the coordinates the predicates look at
+        cols = [0, 1, 2, 26] if S == 45 else [0, 1, 2, 16]
+        for r in range(96):
+            if r % 3:
+                n[r, cols[rng.integers(len(cols))]] = special[rng.integers(len(special))]
+            if r % 7 == 0:
+                n[r, 0] = special[rng.integers(len(special))]
+        o = gi.walker_like_obs(rng, 96, S); a = rng.uniform(-1, 1, (96, 6)).astype(np.float32)
+        d = get_termination_fn(t)(o, a, n)
+        out[t + "::next_obs"] = n
+        out[t + "::done"] = np.asarray(d).astype(bool).reshape(96, 1)
+    try:
+        get_termination_fn("reacher-x")
+        out["unknown_raises"] = np.array(0)
+    except TypeError:
+        out["unknown_raises"] = np.array(1)
+    save("g5_termination", **out)
+
+
+# ------------------------------------------------------------------- policy cfg
+def policy_cfg(S, A, **over):
+    cfg = dict(gamma=0.99, tau=0.005, update_interval=2, state_dim=S, action_dim=A, penalty_type="none",
+               hidden_sizes=256, max_action=1.0, critic_lr=3e-4, actor_lr=3e-4, gaussian_noise_std=1.0,
+               penalize_fake=0, src_ratio=1, trg_ratio=1, src_rollout_length=1, trg_rollout_length=1,
+               use_src_sa_to_get_target_next_state=1, env_filter=10.0, rollout_from_src=0, fake_batch_scale=0.5,
+               advantage=0, scale_Q=1, weight=2.5, bc_coef=1.0, q_weighted=1, filter_bad_rollout=1,
+               penalty_coef=0.1, **DYN_CFG)
+    cfg.update(over)
+    return cfg
+
+
+def load_mlp(mod, p):
+    sd = mod.state_dict()
+    for k, v in p.items():
+        assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+        sd[k] = torch.from_numpy(v)
+    mod.load_state_dict(sd)
+
+
+def make_policy(cfg, seed):
+    S, A = cfg["state_dim"], cfg["action_dim"]
+    pol = MOBODY(cfg, torch.device("cpu"))
+    pa = {"network." + k: v for k, v in gi.mlp_params(seed, S, A).items()}
+    pq = {}
+    for j, sd_ in ((1, seed + 1), (2, seed + 2)):
+        pq.update({f"network{j}." + k: v for k, v in gi.mlp_params(sd_, S + A, 1).items()})
+    pv = {"network." + k: v for k, v in gi.mlp_params(seed + 3, S, 1).items()}
+    load_mlp(pol.policy, pa); load_mlp(pol.q_funcs, pq); load_mlp(pol.target_q_funcs, pq); load_mlp(pol.v_func, pv)
+    return pol, pa, pq, pv
+
+
+# --------------------------------------------------------------------------- G6
+def g6():
+    S, A, B = 17, 6, 40
+    m, p = load_dyn(S, A, 201, 0, 0.85)
+    for H, use_trg, tag in ((1, True, "h1"), (5, True, "h5"), (3, False, "h3_nopen")):
+        cfg = policy_cfg(S, A)
+        pol, pa, _, _ = make_policy(cfg, 301)
+        dyn = MOBODYEnsembleDynamics(cfg, m, None, None, get_termination_fn("walker2d-medium-v2"), penalty_coef=0.1)
+        pol.dynamics = dyn
+        rng = np.random.default_rng(202)
+        init = gi.walker_like_obs(rng, B, S)
+        # pick env_filter at the median step-1 penalty so the filter really drops rows
+        with RngTap(1) as tap, torch.no_grad():
+            a0 = pol.select_action(torch.from_numpy(init), pol.policy, cuda=True).reshape(-1, A)
+            _, _, _, info = dyn.step(torch.from_numpy(init), a0)
+        cfg["env_filter"] = float(np.median(info["penalty"].numpy()))
+        np.random.seed(77)
+        with RngTap(203) as tap:
+            tr, inf = pol.rollout(torch.from_numpy(init), H, use_trg)
+        out = dict(S=S, A=A, H=H, use_trg=int(use_trg), dyn_seed=201, actor_seed=301, alive_val=0.85,
+                   wsum_dyn=gi.checksum(p), wsum_actor=gi.checksum(pa), env_filter=cfg["env_filter"], init=init,
+                   n_steps=len(tap.eps), num_transitions=inf["num_transitions"], reward_mean=inf["reward_mean"])
+        for t, (e, i) in enumerate(zip(tap.eps, tap.idx)):
+            out[f"eps{t}"] = e; out[f"idx{t}"] = i
+        for k, v in tr.items():
+            out["out_" + k] = v.numpy()
+        print("rollout", tag, "steps", len(tap.eps), "rows", [e.shape[1] for e in tap.eps], "kept", len(tr["obss"]))
+        save(f"g6_rollout_{tag}", **out)
+
+
+# --------------------------------------------------------------------------- G7
+class FixedRB:
+    """Stands in for ReplayBuffer.sample (utils.py:127-148) with preset rows; counts calls."""
+
+    def __init__(self, rows):
+        self.rows = [torch.from_numpy(np.asarray(r)) for r in rows]
+        self.size = len(self.rows[0]); self.calls = []
+
+    def sample(self, n):
+        self.calls.append(n)
+        assert n <= self.size
+        return tuple(r[:n].clone() for r in self.rows)
+
+    def add_batch(self, b):
+        pass
+
+
+def g7():
+    S, A, bs = 17, 6, 32
+    variants = dict(default={}, noqw=dict(q_weighted=0), adv=dict(advantage=1), noscale=dict(scale_Q=0),
+                    nofake=dict(fake_batch_scale=0), par=dict(penalty_type="par"), bc05=dict(bc_coef=0.05, trg_ratio=0.5))
+    for tag, over in variants.items():
+        cfg = policy_cfg(S, A, **over)
+        pol, pa, pq, pv = make_policy(cfg, 401)
+        src = FixedRB(gi.batch(501, 64, S, A)); tar = FixedRB(gi.batch(502, 64, S, A)); fake = FixedRB(gi.batch(503, 64, S, A))
+        pol.fake_replay_buffer = fake
+        out = dict(S=S, A=A, bs=bs, seed=401, wsum_actor=gi.checksum(pa), wsum_q=gi.checksum(pq), wsum_v=gi.checksum(pv),
+                   cfg_keys=np.array(sorted(over)), cfg_vals=np.array([str(over[k]) for k in sorted(over)]))
+        if tag == "par":
+            m, p = load_dyn(S, A, 201, 0, 0.85)
+            pol.dynamics = MOBODYEnsembleDynamics(cfg, m, None, None, get_termination_fn("walker2d-medium-v2"), penalty_coef=0.1)
+            out["wsum_dyn"] = gi.checksum(p)
+        rec = dict(q_loss=[], pi_loss=[], bc_loss=[])
+        for nm, key in (("update_q_functions", "q_loss"), ("update_q_functions_1", "q_loss"), ("update_policy", "pi_loss"),
+                        ("update_policy_1", "pi_loss"), ("bc_loss", "bc_loss")):
+            def mk(orig, key):
+                def f(*a, **k):
+                    o = orig(*a, **k); rec[key].append(float(o.detach())); return o
+                return f
+            setattr(pol, nm, mk(getattr(pol, nm), key))
+        pol.total_it = 1                       # -> 2,3: no rollout refresh, no DARA warm-up
+        dummy = types.SimpleNamespace(log=lambda *a, **k: None)
+        for step in (1, 2):
+            np.random.seed(9)
+            with RngTap(600 + step) as tap:
+                pol.train(src, tar, bs, None, dummy)
+            if tag == "par":
+                out[f"par_eps{step}"] = tap.eps[0]; out[f"par_idx{step}"] = tap.idx[0]
+            for nm, mod in (("q", pol.q_funcs), ("actor", pol.policy), ("qt", pol.target_q_funcs), ("v", pol.v_func)):
+                for k, v in mod.state_dict().items():
+                    out[f"s{step}_{nm}_p::{k}"] = sub(v.numpy())
+            for nm, mod in (("q", pol.q_funcs), ("actor", pol.policy), ("v", pol.v_func)):
+                for k, v in mod.named_parameters():
+                    if v.grad is not None:
+                        g = v.grad.numpy()
+                        out[f"s{step}_{nm}_g::{k}"] = sub(g)
+                        out[f"s{step}_{nm}_gsum::{k}"] = np.array([g.astype(np.float64).sum(), (g.astype(np.float64) ** 2).sum()])
+        out["q_loss"] = np.array(rec["q_loss"]); out["pi_loss"] = np.array(rec["pi_loss"]); out["bc_loss"] = np.array(rec["bc_loss"])
+        out["calls_src"] = np.array(src.calls); out["calls_tar"] = np.array(tar.calls); out["calls_fake"] = np.array(fake.calls)
+        print("train", tag, "q_loss", rec["q_loss"], "pi_loss", rec["pi_loss"], "calls", src.calls, tar.calls, fake.calls)
+        save(f"g7_train_{tag}", **out)
+
+
+# --------------------------------------------------------------------------- G8
+def g8():
+    S, A, cap = 5, 2, 50
+    out = {}
+    rb = ref_utils.ReplayBuffer(S, A, "cpu", max_size=cap)
+    rng = np.random.default_rng(8)
+    log = []
+    for ci, M in enumerate([20, 20, 20, 10, 50, 7, 43, 49, 3]):
+        b = dict(obss=torch.from_numpy(rng.standard_normal((M, S)).astype(np.float32)),
+                 next_obss=torch.from_numpy(rng.standard_normal((M, S)).astype(np.float32)),
+                 actions=torch.from_numpy(rng.standard_normal((M, A)).astype(np.float32)),
+                 rewards=torch.from_numpy(rng.standard_normal((M, 1)).astype(np.float32)),
+                 terminals=torch.from_numpy((rng.uniform(size=(M, 1)) > 0.7).astype(np.float32)))
+        for k, v in b.items():
+            out[f"add{ci}_{k}"] = v.numpy()
+        rb.add_batch(b)
+        log.append((M, rb.ptr, rb.size))
+        out[f"after{ci}_state"] = rb.state.numpy().copy(); out[f"after{ci}_action"] = rb.action.numpy().copy()
+        out[f"after{ci}_next_state"] = rb.next_state.numpy().copy(); out[f"after{ci}_reward"] = rb.reward.numpy().copy()
+        out[f"after{ci}_not_done"] = rb.not_done.numpy().copy()
+    rb.add_batch(None)
+    out["log"] = np.array(log)
+    np.random.seed(123)
+    smp = rb.sample(16)
+    np.random.seed(123)
+    out["sample_ind"] = np.random.randint(0, rb.size, size=16)
+    for k, v in zip(("state", "action", "next_state", "reward", "not_done"), smp):
+        out["sample_" + k] = v.numpy()
+    # the index stream the driver sees for seed 0 (train_mobody.py:442 + mobody.py:399-400)
+    np.random.seed(0)
+    out["stream_seed0"] = np.concatenate([np.random.randint(0, 1000000, size=8), np.random.randint(0, 5000, size=8)])
+    # convert_D4RL (utils.py:173-193)
+    ds = dict(observations=rng.standard_normal((30, S)).astype(np.float32), actions=rng.standard_normal((30, A)).astype(np.float32),
+              next_observations=rng.standard_normal((30, S)).astype(np.float32), rewards=rng.standard_normal(30).astype(np.float32),
+              terminals=(rng.uniform(size=30) > 0.8))
+    rb2 = ref_utils.ReplayBuffer(S, A, "cpu", max_size=cap)
+    rb2.convert_D4RL(ds)
+    for k, v in ds.items():
+        out["d4rl_" + k] = v
+    out["d4rl_size"] = np.array(rb2.size); out["d4rl_not_done"] = rb2.not_done.numpy(); out["d4rl_reward"] = rb2.reward.numpy()
+    save("g8_replay", **out)
+
+
+# --------------------------------------------------------------------------- G9
+def g9():
+    S, A, bs = 17, 6, 24
+    cfg = policy_cfg(S, A, penalty_type="dara")
+    pol, _, _, _ = make_policy(cfg, 401)
+    pc = {}
+    pc.update({"sa_classifier." + k: v for k, v in gi.mlp_params(701, S + A, 2).items()})
+    pc.update({"sas_classifier." + k: v for k, v in gi.mlp_params(702, 2 * S + A, 2).items()})
+    load_mlp(pol.classifier, pc)
+    s, a, s2, _, _ = gi.batch(703, 64, S, A)
+    with torch.no_grad():
+        ps, pa_ = pol.classifier(torch.from_numpy(s), torch.from_numpy(a), torch.from_numpy(s2), with_noise=False)
+        sp, ap = torch.softmax(ps, -1), torch.softmax(pa_, -1)
+        ls, la = torch.log(sp + 1e-10), torch.log(ap + 1e-10)
+        dr = (ls[:, 1:] - la[:, 1:] - ls[:, :1] + la[:, :1]).clamp(-10, 10)
+    out = dict(S=S, A=A, seed_sa=701, seed_sas=702, wsum=gi.checksum(pc), s=s, a=a, s2=s2, probs_sas=ps.numpy(),
+               probs_sa=pa_.numpy(), delta_r=dr.numpy())
+    # one update_classifier step with recorded permutation / noise (mobody.py:146-181)
+    src = FixedRB(gi.batch(704, 64, S, A)); tar = FixedRB(gi.batch(705, 64, S, A))
+    taps = dict(perm=None, noise=[])
+    o_perm, o_randn = torch.randperm, torch.randn_like
+
+    def randperm(n, **k):
+        p = o_perm(n, **k); taps["perm"] = p.numpy().copy(); return p
+
+    def randn_like(x, **k):
+        e = o_randn(x); taps["noise"].append(e.numpy().copy()); return e
+
+    torch.randperm, torch.randn_like = randperm, randn_like
+    try:
+        torch.manual_seed(5)
+        loss_sa, loss_sas = pol.update_classifier(src, tar, bs, None)
+    finally:
+        torch.randperm, torch.randn_like = o_perm, o_randn
+    out.update(bs=bs, perm=taps["perm"], noise_sas=taps["noise"][0], noise_sa=taps["noise"][1], loss_sa=float(loss_sa),
+               loss_sas=float(loss_sas))
+    for k, v in pol.classifier.named_parameters():
+        out["cls_g::" + k] = sub(v.grad.numpy()); out["cls_p::" + k] = sub(v.detach().numpy())
+    save("g9_dara", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9"]
+    for w in which:
+        globals()[w]()

@@ -1,0 +1,69 @@
+"""Helpers shared by the oracle-vs-golden and HIP-vs-oracle tests."""
+import os
+
+import numpy as np
+
+import gen_inputs as gi
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def sub(x):
+    """Same thinning rule as make_golden.sub."""
+    f = np.asarray(x).reshape(-1)
+    return f[::13].copy() if f.size > 4096 else f.copy()
+
+
+def dyn_params_for(g):
+    """Regenerate the dynamics weights a g234/g6 fixture was produced with and verify the checksum."""
+    seed = int(g["seed"]) if "seed" in g else int(g["dyn_seed"])
+    S, A = int(g["S"]), int(g["A"])
+    p = gi.dyn_params(seed, S, A)
+    ad = int(g["alive_dim"]) if "alive_dim" in g else 0
+    p["transition3.bias"][:, 0, ad] += np.float32(float(g["alive_val"]))
+    want = float(g["wsum"]) if "wsum" in g else float(g["wsum_dyn"])
+    assert abs(gi.checksum(p) - want) <= 1e-9 * abs(want), "weight generator drifted from the fixture"
+    return p
+
+
+def policy_params(seed, S, A):
+    pa = {"network." + k: v for k, v in gi.mlp_params(seed, S, A).items()}
+    pq = {}
+    for j, sd in ((1, seed + 1), (2, seed + 2)):
+        pq.update({f"network{j}." + k: v for k, v in gi.mlp_params(sd, S + A, 1).items()})
+    pv = {"network." + k: v for k, v in gi.mlp_params(seed + 3, S, 1).items()}
+    return pa, pq, pv
+
+
+def policy_cfg(S, A, **over):
+    cfg = dict(gamma=0.99, tau=0.005, update_interval=2, state_dim=S, action_dim=A, penalty_type="none",
+               hidden_sizes=256, max_action=1.0, critic_lr=3e-4, actor_lr=3e-4, gaussian_noise_std=1.0,
+               penalize_fake=0, src_ratio=1, trg_ratio=1, src_rollout_length=1, trg_rollout_length=1,
+               use_src_sa_to_get_target_next_state=1, env_filter=10.0, rollout_from_src=0, fake_batch_scale=0.5,
+               advantage=0, scale_Q=1, weight=2.5, bc_coef=1.0, q_weighted=1, filter_bad_rollout=1,
+               penalty_coef=0.1, mopo=0, latent_reward=0, encoder_loss_coef=1, domain_loss_coef=0.0,
+               cycle_loss_coef=0.3)
+    cfg.update(over)
+    return cfg
+
+
+G7_VARIANTS = dict(default={}, noqw=dict(q_weighted=0), adv=dict(advantage=1), noscale=dict(scale_Q=0),
+                   nofake=dict(fake_batch_scale=0), par=dict(penalty_type="par"), bc05=dict(bc_coef=0.05, trg_ratio=0.5))
+
+
+def g7_batch(cfg, bs, S, A, src_reward_override=None):
+    """Assemble the mixed batch the way mobody.py:399-400,516-529 does from the FixedRB presets."""
+    src = gi.batch(501, 64, S, A); tar = gi.batch(502, 64, S, A); fake = gi.batch(503, 64, S, A)
+    ns, nt = int(cfg["src_ratio"] * bs), int(cfg["trg_ratio"] * bs)
+    nf = int(cfg["fake_batch_scale"] * bs)
+    parts = [[x[:ns].copy() for x in src], [x[:nt].copy() for x in tar]]
+    if src_reward_override is not None:
+        parts[0][3] = src_reward_override
+    if cfg["fake_batch_scale"] != 0:
+        parts.append([x[:nf].copy() for x in fake])
+    batch = tuple(np.concatenate([p[i] for p in parts], 0) for i in range(5))
+    return batch, ns + nt

@@ -1,0 +1,185 @@
+"""Pin the CPU oracle (oracle/mobody_oracle.py) against golden vectors produced by the real reference.
+
+CPU-only (-m "not gpu").  Tolerances: the oracle uses the same ATen CPU kernels as the
+reference, so most outputs agree to ~1e-6; 2e-5 relative is asserted to stay robust to
+BLAS blocking differences between hosts.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import mobody_oracle as O
+
+RT, AT = 2e-5, 2e-6
+
+
+def close(a, b, rtol=RT, atol=AT):
+    np.testing.assert_allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=atol)
+
+
+def test_g1_ensemble_linear():
+    g = gu.load("g1_ensemble_linear")
+    W, b = O.T(g["W"]), O.T(g["b"])
+    close(O.ensemble_linear(O.T(g["x2"]), W, b), g["y2"])
+    close(O.ensemble_linear(O.T(g["x3"]), W, b), g["y3"])
+
+
+@pytest.mark.parametrize("tag", ["walker", "ant", "pen"])
+def test_g234_dynamics(tag):
+    g = gu.load(f"g234_dynamics_{tag}")
+    p = O.to_torch(gu.dyn_params_for(g))
+    obs, act, nxt = O.T(g["obs"]), O.T(g["act"]), O.T(g["nxt"])
+    with torch.no_grad():
+        mt, zmu, zlv = O.dyn_forward(p, obs, act, True)
+        ms, _, _ = O.dyn_forward(p, obs, act, False)
+        rmu, rlv = O.dyn_reward(p, obs, act, nxt)
+    close(mt, g["mean_trg"]); close(ms, g["mean_src"]); close(zmu, g["zs_mu"]); close(zlv, g["zs_logvar"])
+    close(rmu, g["r_mu"]); close(rlv, g["r_logvar"])
+    task = str(g["task"])
+    for up in (1, 0):
+        for ut in (1, 0):
+            k = f"step_p{up}_t{ut}_"
+            with torch.no_grad():
+                st = O.dyn_step(p, obs, act, g[k + "eps"], g[k + "idx"], task, penalty_coef=0.1,
+                                use_penalty=bool(up), use_trg=bool(ut))
+            close(st["next_obs"], g[k + "next_obs"]); close(st["reward"], g[k + "reward"])
+            close(st["penalty"], g[k + "penalty"]); close(st["raw_reward"], g[k + "raw_reward"])
+            close(st["mean"], g[k + "samples"])
+            assert (st["terminal"] == g[k + "terminal"]).all()
+    assert 0 < g["step_p1_t1_terminal"].sum() < len(obs)      # fixture exercises both outcomes
+
+
+def test_g5_termination():
+    g = gu.load("g5_termination")
+    tasks = sorted({k.split("::")[0] for k in g if "::" in k})
+    assert len(tasks) == 10
+    for t in tasks:
+        n = g[t + "::next_obs"]
+        d = O.termination(t, n, None, n)
+        assert d.shape == (len(n), 1) and d.dtype == bool
+        assert (d == g[t + "::done"]).all(), t
+    assert int(g["unknown_raises"]) == 1
+    with pytest.raises(TypeError):
+        O.termination("reacher-x", np.zeros((1, 3)), None, np.zeros((1, 3)))
+
+
+@pytest.mark.parametrize("tag", ["h1", "h5", "h3_nopen"])
+def test_g6_rollout(tag):
+    g = gu.load(f"g6_rollout_{tag}")
+    S, A = int(g["S"]), int(g["A"])
+    p = O.to_torch(gu.dyn_params_for(g))
+    pa, _, _ = gu.policy_params(int(g["actor_seed"]), S, A)
+    cfg = gu.policy_cfg(S, A, env_filter=float(g["env_filter"]))
+    n = int(g["n_steps"])
+    with torch.no_grad():
+        res, info = O.rollout(O.to_torch(pa), p, g["init"], int(g["H"]), [g[f"eps{t}"] for t in range(n)],
+                              [g[f"idx{t}"] for t in range(n)], "walker2d-medium-v2", cfg,
+                              use_trg=bool(int(g["use_trg"])), penalty_coef=0.1)
+    assert info["num_transitions"] == int(g["num_transitions"])
+    close(info["reward_mean"], float(g["reward_mean"]))
+    for k in ("obss", "next_obss", "actions", "rewards", "terminals", "penalty"):
+        assert res[k].shape == g["out_" + k].shape, k
+        close(res[k], g["out_" + k])
+
+
+@pytest.mark.parametrize("tag", list(gu.G7_VARIANTS))
+def test_g7_train_step(tag):
+    g = gu.load(f"g7_train_{tag}")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    cfg = gu.policy_cfg(S, A, **gu.G7_VARIANTS[tag])
+    pa, pq, pv = gu.policy_params(int(g["seed"]), S, A)
+    st = O.TrainState(pa, pq, pv)
+    dyn = None
+    if tag == "par":
+        dyn = O.to_torch(gu.dyn_params_for(dict(S=S, A=A, dyn_seed=201, alive_val=0.85, wsum_dyn=g["wsum_dyn"])))
+    for step in (1, 2):
+        override = None
+        if tag == "par":     # mobody.py:428-434
+            src = gu.gi.batch(501, 64, S, A)
+            with torch.no_grad():
+                stp = O.dyn_step(dyn, src[0][:bs], src[1][:bs], g[f"par_eps{step}"], g[f"par_idx{step}"],
+                                 "walker2d-medium-v2", penalty_coef=0.1)
+                pen = ((O.T(src[2][:bs]) - stp["next_obs"]) ** 2).mean(1, keepdim=True)
+            override = src[3][:bs] - cfg["penalty_coef"] * pen.numpy()
+        batch, n_true = gu.g7_batch(cfg, bs, S, A, override)
+        out = O.train_step(st, batch, n_true, cfg)
+        close(out["q_loss"], g["q_loss"][step - 1], rtol=1e-5)
+        close(out["pi_loss"], g["pi_loss"][step - 1], rtol=1e-5)
+        close(out["bc_loss"], g["bc_loss"][step - 1], rtol=1e-5)
+        for nm, grads in (("q", out["q_grads"]), ("actor", out["actor_grads"])):
+            for k, v in grads.items():
+                key = f"s{step}_{nm}_g::{k}"
+                close(gu.sub(v.numpy()), g[key], rtol=2e-4, atol=2e-7)
+        for nm, params in (("q", st.q), ("actor", st.actor), ("qt", st.q_targ), ("v", st.v)):
+            for k, v in params.items():
+                close(gu.sub(v.numpy()), g[f"s{step}_{nm}_p::{k}"], rtol=1e-5, atol=1e-6)
+
+
+def test_g8_ring_append_and_sample():
+    g = gu.load("g8_replay")
+    cap, S, A = 50, 5, 2
+    buf = dict(state=np.zeros((cap, S), np.float32), action=np.zeros((cap, A), np.float32),
+               next_state=np.zeros((cap, S), np.float32), reward=np.zeros((cap, 1), np.float32),
+               not_done=np.zeros((cap, 1), np.float32))
+    ptr = size = 0
+    for ci, (M, want_ptr, want_size) in enumerate(g["log"]):
+        segs, ptr, size = O.ring_append_plan(ptr, size, cap, int(M))
+        for dst, src, ln in segs:
+            buf["state"][dst:dst + ln] = g[f"add{ci}_obss"][src:src + ln]
+            buf["action"][dst:dst + ln] = g[f"add{ci}_actions"][src:src + ln]
+            buf["next_state"][dst:dst + ln] = g[f"add{ci}_next_obss"][src:src + ln]
+            buf["reward"][dst:dst + ln] = g[f"add{ci}_rewards"][src:src + ln]
+            buf["not_done"][dst:dst + ln] = 1.0 - g[f"add{ci}_terminals"][src:src + ln]
+        assert (ptr, size) == (int(want_ptr), int(want_size)), ci
+        for k in buf:
+            assert (buf[k] == g[f"after{ci}_{k}"]).all(), (ci, k)
+    np.random.seed(123)
+    ind = np.random.randint(0, size, size=16)
+    assert (ind == g["sample_ind"]).all()
+    for k in buf:
+        assert (buf[k][ind] == g["sample_" + k]).all()
+    np.random.seed(0)
+    stream = np.concatenate([np.random.randint(0, 1000000, size=8), np.random.randint(0, 5000, size=8)])
+    assert (stream == g["stream_seed0"]).all()
+    assert int(g["d4rl_size"]) == 30
+    close(g["d4rl_not_done"], 1.0 - g["d4rl_terminals"].reshape(-1, 1).astype(np.float32))
+
+
+def test_g9_dara():
+    g = gu.load("g9_dara")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    pc = {}
+    pc.update({"sa_classifier." + k: v for k, v in gu.gi.mlp_params(int(g["seed_sa"]), S + A, 2).items()})
+    pc.update({"sas_classifier." + k: v for k, v in gu.gi.mlp_params(int(g["seed_sas"]), 2 * S + A, 2).items()})
+    assert abs(gu.gi.checksum(pc) - float(g["wsum"])) < 1e-9 * abs(float(g["wsum"]))
+    p = O.to_torch(pc)
+    with torch.no_grad():
+        ps, pa = O.classifier_probs(p, O.T(g["s"]), O.T(g["a"]), O.T(g["s2"]))
+        close(ps, g["probs_sas"]); close(pa, g["probs_sa"])
+        close(O.dara_delta_r(p, g["s"], g["a"], g["s2"]), g["delta_r"], rtol=1e-4, atol=1e-5)
+    # one classifier update (mobody.py:146-181): rows src|tar, labels 0|1, permuted
+    src = gu.gi.batch(704, 64, S, A); tar = gu.gi.batch(705, 64, S, A)
+    perm = g["perm"]
+    cat = [np.concatenate([src[i][:bs], tar[i][:bs]], 0)[perm] for i in range(3)]
+    label = np.concatenate([np.zeros(bs), np.ones(bs)])[perm]
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    loss = O.classifier_loss(pr, cat[0], cat[1], cat[2], label, g["noise_sas"], g["noise_sa"], 1.0)
+    close(float(loss), float(g["loss_sa"]) + float(g["loss_sas"]), rtol=1e-5)
+    grads = torch.autograd.grad(loss, list(pr.values()))
+    for (k, _), gr in zip(pr.items(), grads):
+        close(gu.sub(gr.numpy()), g["cls_g::" + k], rtol=2e-4, atol=2e-7)
+
+
+def test_philox_known_answer():
+    """Philox4x32-10 known-answer vectors from the Random123 distribution (kat_vectors)."""
+    r = O.philox4x32(0, 0, 0, 0, 0, 0)
+    assert [int(x) for x in r] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    r = O.philox4x32(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)
+    assert [int(x) for x in r] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    r = O.philox4x32(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0)
+    assert [int(x) for x in r] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    z = O.rng_normal(1, 2, 3, 200000)
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    i = O.rng_index(1, 2, 3, 100000, 5)
+    assert i.min() == 0 and i.max() == 4 and abs(np.bincount(i)[0] / 1e5 - 0.2) < 0.01
