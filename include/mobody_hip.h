@@ -1,0 +1,193 @@
+/* mobody_hip.h -- C ABI of the MI355X-native MOBODY hot path (libmobody_hip.so, gfx950).
+ *
+ * The reference (github guoyihonggyh/MOBODY-...) is pure Python/PyTorch and has no FFI
+ * of its own; these entry points are what a binding for its hot path binds instead of
+ * the ATen op sequences at the cited reference sites (paths relative to the reference):
+ *
+ *   mobody_dyn_forward   <- MOBODYModule.forward_trg/forward_src  algo/dynamics/mobody_module.py:315-330
+ *   mobody_dyn_step      <- MOBODYEnsembleDynamics.step           algo/dynamics/mobody_dynamics.py:193-265
+ *                           (+ termination predicates             algo/mb_utils/terminal_funs.py:10-149)
+ *   mobody_mlp3_forward  <- Policy / DoubleQFunc / ValueFunc fwd  algo/offline_offline/mobody.py:35-83
+ *   mobody_gather_batch  <- ReplayBuffer.sample x3 + torch.cat    algo/utils.py:127-148, mobody.py:399-400,516-529
+ *   mobody_ring_append   <- ReplayBuffer.add_batch (+ filter)     algo/utils.py:43-92, mobody.py:468,648-653
+ *   mobody_critic_step   <- update_q_functions + backward         mobody.py:189-208,544-547
+ *   mobody_actor_forward / mobody_actor_backward
+ *                        <- update_policy + bc_loss + backward    mobody.py:246-276,314-345,555-572
+ *   mobody_adam_polyak   <- Adam.step + update_target             mobody.py:127-131,183-187,548,552,573
+ *   mobody_rng_*         <- torch.normal / np.random.choice / np.random.randint draws
+ *                           (mobody_dynamics.py:220, mobody_module.py:355-357, utils.py:128)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch `tensor.data_ptr()`), fp32
+ *     row-major contiguous unless stated; the caller owns every buffer; the library
+ *     allocates nothing and keeps no state between calls (no context object needed);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call
+ *     synchronises; calls are graph-capturable;
+ *   - every function returns 0 on success, a negative MOBODY_E* code otherwise and
+ *     never throws; mobody_last_error() gives the text (thread local);
+ *   - not thread safe per stream: one caller per stream.
+ *   - network weights are passed as PACKED blobs whose layout is computed by
+ *     mobody_dyn_layout / mobody_mlp_layout (zero padded [K_pad][N_pad] per member);
+ *     the host-side mirror packs/unpacks the reference's state_dict tensors.
+ */
+#ifndef MOBODY_HIP_H
+#define MOBODY_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOBODY_ABI_VERSION 1
+#define MOBODY_E_ARG (-1)      /* bad argument (dims, null pointer, unsupported size) */
+#define MOBODY_E_LAUNCH (-2)   /* hipLaunch / runtime error */
+#define MOBODY_E_UNSUPPORTED (-3)
+
+#define MOBODY_HIDDEN 256
+#define MOBODY_ENSEMBLE 7
+#define MOBODY_LATENT 16
+
+/* termination predicate ids (terminal_funs.py:123-149 dispatch, resolved on the host) */
+enum { MOBODY_TERM_NEVER = 0, MOBODY_TERM_HALFCHEETAH = 1, MOBODY_TERM_HOPPER = 2, MOBODY_TERM_ANT = 3,
+       MOBODY_TERM_WALKER2D = 4, MOBODY_TERM_HUMANOID = 5, MOBODY_TERM_PEN = 6 };
+
+/* ---- packed layouts -------------------------------------------------------------------- */
+typedef struct MobodyLayer {
+  int32_t in_dim, out_dim;   /* logical dims actually used by the hot path */
+  int32_t Kp, Np;            /* padded dims of the packed matrix W[member][Kp][Np] */
+  int64_t w_off, b_off;      /* float offsets of member 0 inside the blob; bias is [member][Np] */
+} MobodyLayer;
+
+enum { MOBODY_DL_ZS1 = 0, MOBODY_DL_ZS2, MOBODY_DL_ZS3, MOBODY_DL_ZA_SRC1, MOBODY_DL_ZA_SRC2, MOBODY_DL_ZA_TRG1,
+       MOBODY_DL_ZA_TRG2, MOBODY_DL_TR1, MOBODY_DL_TR2, MOBODY_DL_TR3, MOBODY_DL_RW1, MOBODY_DL_RW2, MOBODY_DL_RW3,
+       MOBODY_DL_COUNT };
+
+typedef struct MobodyDynLayout {
+  int32_t S, A, E, _pad;
+  MobodyLayer layer[MOBODY_DL_COUNT];
+  int64_t total_floats;
+} MobodyDynLayout;
+
+/* 3-layer MLP (in -> 256 -> 256 -> out), `members` independent copies (twin-Q = 2).
+ * Parameter blob, per member: W1[Kp1][256] b1[256] W2[256][256] b2[256] W3[256][Np3] b3[Np3]
+ * (W stored [in][out], i.e. the transpose of nn.Linear.weight).  The same layout is used for
+ * gradients and both Adam moments.  The "T" blob holds the transposes the backward pass
+ * streams as MFMA B operands: W3T[Np3][256] W2T[256][256] W1T[256][Np1t] per member. */
+typedef struct MobodyMlpLayout {
+  int32_t in_dim, out_dim, members, Kp1, Np3, Np1t;
+  int64_t w1, b1, w2, b2, w3, b3;   /* float offsets inside one member */
+  int64_t member_floats, total_floats;
+  int64_t w3t, w2t, w1t;            /* float offsets inside one member of the T blob */
+  int64_t t_member_floats, t_total_floats;
+} MobodyMlpLayout;
+
+const char* mobody_last_error(void);
+int mobody_abi_version(void);
+int mobody_dyn_layout(int S, int A, MobodyDynLayout* out);
+int mobody_mlp_layout(int in_dim, int out_dim, int members, MobodyMlpLayout* out);
+
+/* ---- counter based RNG (Philox4x32-10; CPU twin: oracle/mobody_oracle.py rng_*) ---------- */
+int mobody_rng_normal(uint32_t seed, uint32_t stream_id, uint32_t call, int64_t n, float* out, void* stream);
+int mobody_rng_index(uint32_t seed, uint32_t stream_id, uint32_t call, int64_t n, uint32_t bound, int32_t* out,
+                     void* stream);
+
+/* ---- ensemble dynamics ----------------------------------------------------------------- */
+/* mean[E][B][S] = forward_trg/forward_src(obs, act) in inference mode. */
+int mobody_dyn_forward(const float* dyn_blob, int S, int A, const float* obs, const float* act, int64_t B,
+                       int use_trg, float* mean, void* stream);
+
+/* floats of scratch mobody_dyn_step needs for a batch of B rows */
+int64_t mobody_dyn_step_workspace(int S, int A, int64_t B);
+
+/* One imagined transition for B rows (A.1 of SURVEY.md).
+ *   noise      [E][B][S] unit normals, or NULL -> generated on device from (seed, call)
+ *   elite_idx  [B] member id per row,   or NULL -> elites[philox % n_elites]
+ *   alive      [B] optional uint8 mask (NULL = all alive); dead rows are computed but flagged
+ *              terminal=1 so an on-device multi-step rollout can keep fixed row indices
+ *   elites     HOST array of n_elites member ids (MOBODYModule.elites), used when elite_idx is NULL
+ *   outputs    next_obs[B][S], reward[B], terminal[B] (uint8), penalty[B], raw_reward[B] (nullable)
+ *   mean_out   optional [E][B][S] copy of the ensemble means (info['samples']) */
+int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, const float* obs, const float* act, int64_t B,
+                    const float* noise, const int32_t* elite_idx, const uint8_t* alive, const int32_t* elites,
+                    int n_elites, uint32_t seed,
+                    uint32_t call, float penalty_coef, int use_penalty, int use_trg, float* next_obs, float* reward,
+                    uint8_t* terminal, float* penalty, float* raw_reward, float* mean_out, float* workspace,
+                    void* stream);
+
+/* ---- 3-layer MLP forward (ReLU) -------------------------------------------------------- */
+/* x = concat(src0[rows][n0], src1[rows][n1]) (src1 may be NULL), n0+n1 == in_dim.
+ * out_mode 0: out[m][rows][out_dim] raw;  1: max_action*tanh(.) (Policy.forward mobody.py:68-72).
+ * save_x [rows][Kp1], save_h1/save_h2 [members][rows][256] are optional (backward inputs). */
+int mobody_mlp3_forward(const float* blob, int in_dim, int out_dim, int members, const float* src0, int n0,
+                        const float* src1, int n1, int64_t rows, int out_mode, float max_action, float* out,
+                        float* save_x, float* save_h1, float* save_h2, void* stream);
+
+/* ---- replay gather / ring append ------------------------------------------------------- */
+typedef struct MobodyBufferView {   /* ReplayBuffer fields, algo/utils.py:19-23 */
+  const float* state; const float* action; const float* next_state; const float* reward; const float* not_done;
+} MobodyBufferView;
+
+/* Concatenate rows idx_k of up to three buffers (src | tar | fake order, mobody.py:525-529)
+ * into one minibatch: state[N][S] action[N][A] next_state[N][S] reward[N] not_done[N]. */
+int mobody_gather_batch(const MobodyBufferView* bufs, const int32_t* const* idx, const int64_t* counts, int nbuf,
+                        int S, int A, float* state, float* action, float* next_state, float* reward, float* not_done,
+                        void* stream);
+
+/* Append the rows with keep[i] != 0 (NULL = all), in order, to a ring buffer of `cap` rows at
+ * *ptr_size (device int64[2] = {ptr, size}), reproducing add_batch's single-wrap arithmetic
+ * (utils.py:43-92); not_done = 1 - terminal.  `scan_ws` needs (M + 1024) int32. */
+int mobody_ring_append(float* b_state, float* b_action, float* b_next_state, float* b_reward, float* b_not_done,
+                       int64_t cap, int64_t* ptr_size, int S, int A, const float* obs, const float* act,
+                       const float* next_obs, const float* reward, const uint8_t* terminal, const uint8_t* keep,
+                       int64_t M, int32_t* scan_ws, void* stream);
+
+/* ---- training step --------------------------------------------------------------------- */
+typedef struct MobodyTrainDims {
+  int32_t S, A;
+  int64_t N;          /* rows of the mixed critic batch on this rank */
+  int64_t Nt;         /* leading rows that form the "true" BC batch (src|tar) */
+  int64_t N_global;   /* sum of N over data-parallel ranks (== N on one GPU) */
+  int64_t Nt_global;
+} MobodyTrainDims;
+
+typedef struct MobodyHyper {
+  float gamma, tau, max_action, weight, bc_coef;
+  int32_t q_weighted, scale_q;
+} MobodyHyper;
+
+/* floats of scratch the training calls need */
+int64_t mobody_train_workspace(const MobodyTrainDims* d);
+
+/* Critic loss + gradients (A.2): grad_q (MobodyMlpLayout(S+A,1,2) layout) and loss_out[0] = L_Q of
+ * the LOCAL rows scaled by 1/N_global (sum over ranks == global loss). */
+int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* q_blob,
+                       const float* q_blob_T, const float* qtarg_blob, const float* state, const float* action,
+                       const float* next_state, const float* reward, const float* not_done, float* grad_q,
+                       float* loss_out, float* workspace, void* stream);
+
+/* Actor phase, part 1: forwards + the two batch statistics stats[0]=sum|min Q(s,pi(s))|,
+ * stats[1]=sum|min Q(s_t,a_t)| over LOCAL rows (all-reduce them across ranks before part 2). */
+int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* q_blob,
+                         const float* state, const float* action, float* stats, float* workspace, void* stream);
+
+/* Actor phase, part 2: grad_actor (MobodyMlpLayout(S,A,1)) and loss_out[0]=L_pi, [1]=L_BC (local share). */
+int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
+                          const float* actor_blob_T, const float* q_blob, const float* q_blob_T, const float* state,
+                          const float* action, const float* stats, float* grad_actor, float* loss_out,
+                          float* workspace, void* stream);
+
+/* Adam (torch defaults b1=.9 b2=.999 eps=1e-8) on a packed blob, 1-based step t; optional Polyak
+ * target update target = tau*p + (1-tau)*target (tau < 0 or target == NULL: skip); refreshes the
+ * transposed blob used by the backward kernels (blob_T may be NULL). grad_scale multiplies the
+ * gradient first (1/world for an all-reduced SUM). */
+int mobody_adam_polyak(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad, float* m,
+                       float* v, float* target, int64_t t, float lr, float tau, float grad_scale, void* stream);
+
+/* (Re)build the transposed blob from a parameter blob (after loading a checkpoint). */
+int mobody_mlp_transpose(int in_dim, int out_dim, int members, const float* blob, float* blob_T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOBODY_HIP_H */

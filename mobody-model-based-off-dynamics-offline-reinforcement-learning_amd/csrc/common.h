@@ -1,0 +1,53 @@
+// Host-side helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/mobody_hip.h"
+#include "tile.h"
+
+namespace mobody {
+
+std::string& last_error();
+int fail(int code, const char* fmt, ...);
+
+#define MB_REQUIRE(cond, ...)                                   \
+  do {                                                          \
+    if (!(cond)) return ::mobody::fail(MOBODY_E_ARG, __VA_ARGS__); \
+  } while (0)
+
+#define MB_LAUNCH_OK(what)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = hipGetLastError();                                                       \
+    if (e_ != hipSuccess) return ::mobody::fail(MOBODY_E_LAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
+  } while (0)
+
+constexpr size_t TILE_LDS_BYTES = (size_t)BM * LDX * sizeof(float);   // 66,560 B: one activation image
+
+// Opt a kernel into > 64 KiB of dynamic LDS once per process.
+template <class K>
+inline int allow_big_lds(K kernel, size_t bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)bytes);
+  if (e != hipSuccess) return fail(MOBODY_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  return 0;
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// device-side view of one packed MLP (member 0 pointers + strides), built from MobodyMlpLayout
+struct MlpView {
+  const float *w1, *b1, *w2, *b2, *w3, *b3;
+  int64_t member_floats;
+  int Kp1, Np3, in_dim, out_dim;
+};
+inline MlpView mlp_view(const float* blob, const MobodyMlpLayout& L) {
+  MlpView v;
+  v.w1 = blob + L.w1; v.b1 = blob + L.b1; v.w2 = blob + L.w2; v.b2 = blob + L.b2; v.w3 = blob + L.w3; v.b3 = blob + L.b3;
+  v.member_floats = L.member_floats; v.Kp1 = L.Kp1; v.Np3 = L.Np3; v.in_dim = L.in_dim; v.out_dim = L.out_dim;
+  return v;
+}
+
+}  // namespace mobody

@@ -1,0 +1,273 @@
+// Ensemble-dynamics imagined transition (the "rollout kernel" family).
+//
+//   k_dyn_fwd      mean[e,b,:] = forward_trg/forward_src(obs, act)   mobody_module.py:315-330
+//                  one workgroup = 64 rows x ONE member, the 9 ensemble layers
+//                  (zs1-3, za1-2, transition1-3) chained through one LDS image;
+//                  grid = (ceil(B/64), 7) so even B = 4096 fills the chip (448 WGs).
+//   k_dyn_sample   ensemble std, Gaussian sample of the elite member, pairwise-diff
+//                  penalty, termination predicate                   mobody_dynamics.py:218-256,
+//                                                                    terminal_funs.py:10-113
+//   reward head    generic fused MLP forward (Swish) on [s,a,s']     mobody_module.py:295-302
+//   k_dyn_finalize reward = mean_e r_mu - coef*penalty               mobody_dynamics.py:236,261-263
+//
+// Roofline: k_dyn_fwd / reward head are MFMA-f32 bound (3.36 MFLOP per transition at
+// S=17,A=6 against 240 algorithmic bytes); k_dyn_sample / k_dyn_finalize are HBM-bound
+// streaming kernels over [E,B,S] floats.
+#include "common.h"
+#include "layers.h"
+#include "rng.h"
+
+namespace mobody {
+
+struct DynFwdArgs {
+  const float* blob;
+  MobodyDynLayout L;
+  const float* obs;
+  const float* act;
+  float* mean;        // [E][B][S]
+  long long B;
+  int use_trg;
+};
+
+__global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float Xs[];
+  const int e = blockIdx.y;
+  const long long row0 = (long long)blockIdx.x * BM;
+  const int rows_here = (int)min((long long)BM, a.B - row0);
+  const int S = a.L.S, A = a.L.A;
+  const int lane = lane_id(), w = wave_id();
+  auto Wp = [&](int l) { return a.blob + a.L.layer[l].w_off + (long long)e * a.L.layer[l].Kp * a.L.layer[l].Np; };
+  auto Bp = [&](int l) { return a.blob + a.L.layer[l].b_off + (long long)e * a.L.layer[l].Np; };
+
+  // ---- state encoder: zs = mu-half of zs3(Sw(zs2(Sw(zs1(s)))))   (encode_state :217-225) ----
+  tile_load(Xs, 0, a.obs + row0 * S, S, S, 0, rows_here);
+  tile_zero_cols(Xs, S, a.L.layer[MOBODY_DL_ZS1].Kp);
+  __syncthreads();
+  wide_layer<ACT_SWISH>(Xs, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, NoExtra{});
+  wide_layer<ACT_SWISH>(Xs, Wp(MOBODY_DL_ZS2), Bp(MOBODY_DL_ZS2), HID, NoExtra{});
+
+  // From here to the latent sum every wave works on its own 16 rows: no barriers needed.
+  const int i = lane & 15, q = lane >> 4;
+  float* myrow = Xs + (16 * w + 4 * q) * LDX;       // rows 16w+4q+r, r = 0..3 (C/D map of 16x16 MFMA)
+  f32x4 zs[1];
+  narrow_gemm<1>(Xs, Wp(MOBODY_DL_ZS3), HID, 16, 0, zs);
+  {
+    const float b = Bp(MOBODY_DL_ZS3)[i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { zs[0][r] += b; myrow[r * LDX + i] = zs[0][r]; }
+  }
+  // ---- action encoder on [zs, a]   (encode_trg_action :258-271 / encode_src_action :245-256) ----
+  const int la1 = a.use_trg ? MOBODY_DL_ZA_TRG1 : MOBODY_DL_ZA_SRC1;
+  const int la2 = a.use_trg ? MOBODY_DL_ZA_TRG2 : MOBODY_DL_ZA_SRC2;
+  const int Kza = a.L.layer[la1].Kp;
+  for (int idx = lane; idx < 16 * (Kza - LATENT); idx += 64) {
+    const int r = idx / (Kza - LATENT), c = idx - r * (Kza - LATENT);
+    const int row = 16 * w + r;
+    Xs[row * LDX + LATENT + c] = (c < A && row < rows_here) ? a.act[(row0 + row) * A + c] : 0.f;
+  }
+  f32x4 g[2];
+  narrow_gemm<2>(Xs, Wp(la1), Kza, 32, 0, g);
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const float b = Bp(la1)[16 * n + i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) myrow[r * LDX + 16 * n + i] = activate<ACT_SWISH>(g[n][r] + b);
+  }
+  f32x4 za[1];
+  narrow_gemm<1>(Xs, Wp(la2), 32, 16, 0, za);
+  {
+    const float b = Bp(la2)[i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) myrow[r * LDX + i] = zs[0][r] + za[0][r] + b;     // z_ns = zs + za  (:319,327)
+  }
+  __syncthreads();
+
+  // ---- transition decoder   (encode_transition :287-293) ----
+  wide_layer<ACT_SWISH>(Xs, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, NoExtra{});
+  wide_layer<ACT_SWISH>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, NoExtra{});
+  const float* b3 = Bp(MOBODY_DL_TR3);
+  float* mean = a.mean + ((long long)e * a.B + row0) * S;
+  narrow_layer(Xs, Wp(MOBODY_DL_TR3), HID, a.L.layer[MOBODY_DL_TR3].Np, [&](int row, int col, float v) {
+    if (row < rows_here && col < S) mean[row * S + col] = v + b3[col];
+  });
+}
+
+// ------------------------------------------------------------------------------------------
+struct DynSampleArgs {
+  const float* mean;         // [E][B][S]
+  const float* noise;        // [E][B][S] or null
+  const int32_t* elite_idx;  // [B] or null
+  const uint8_t* alive;      // [B] or null
+  int32_t elites[NENS];
+  int n_elites;
+  uint32_t seed, call;
+  long long B;
+  int S, task;
+  float* next_obs;           // [B][S]
+  float* penalty;            // [B]
+  uint8_t* terminal;         // [B]
+};
+
+__device__ __forceinline__ bool term_predicate(int task, const float* n, int S) {
+  // terminal_funs.py; comparisons with NaN are false exactly as in NumPy
+  bool in_box = true, finite = true, lt100_from1 = true;
+  for (int d = 0; d < S; ++d) {
+    const float x = n[d];
+    in_box = in_box && (x > -100.f) && (x < 100.f);
+    finite = finite && isfinite(x);
+    if (d >= 1) lt100_from1 = lt100_from1 && (x < 100.f);
+  }
+  switch (task) {
+    case MOBODY_TERM_HALFCHEETAH: return !in_box;                                                   // :10-16
+    case MOBODY_TERM_HOPPER: return !(finite && lt100_from1 && (n[0] > 0.7f) && (fabsf(n[1]) < 0.2f));   // :18-30
+    case MOBODY_TERM_ANT: return !(finite && (n[0] >= 0.2f) && (n[0] <= 1.0f));                      // :39-61
+    case MOBODY_TERM_WALKER2D:                                                                       // :63-75
+      return !(in_box && (n[0] > 0.8f) && (n[0] < 2.0f) && (n[1] > -1.0f) && (n[1] < 1.0f));
+    case MOBODY_TERM_HUMANOID: return (n[0] < 1.0f) || (n[0] > 2.0f);                                // :98-104
+    case MOBODY_TERM_PEN: return n[26] < 0.075f;                                                     // :106-113
+    default: return false;
+  }
+}
+
+// one thread per row; rows are contiguous [S]-float segments so a wave streams 64*S floats per member
+__global__ __launch_bounds__(256) void k_dyn_sample(DynSampleArgs a) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int S = a.S;
+  int e_sel;
+  if (a.elite_idx) e_sel = a.elite_idx[b];
+  else e_sel = a.elites[rng_index_at(a.seed, STREAM_ELITE, a.call, (uint64_t)b, (uint32_t)a.n_elites)];
+  float sq[NENS];
+#pragma unroll
+  for (int e = 0; e < NENS; ++e) sq[e] = 0.f;
+  float* nxt = a.next_obs + b * S;
+  for (int d = 0; d < S; ++d) {
+    float mval[NENS], avg = 0.f, msel = 0.f;
+#pragma unroll
+    for (int e = 0; e < NENS; ++e) {
+      mval[e] = a.mean[((long long)e * a.B + b) * S + d];
+      avg += mval[e];
+      msel = (e == e_sel) ? mval[e] : msel;
+    }
+    avg *= (1.f / NENS);
+    float var = 0.f;
+#pragma unroll
+    for (int e = 0; e < NENS; ++e) { const float t = mval[e] - avg; var += t * t; if (d < S - 1) sq[e] += t * t; }
+    const float sd = sqrtf(var * (1.f / (NENS - 1)));                      // torch.std: unbiased (:218)
+    float eps;
+    if (a.noise) eps = a.noise[((long long)e_sel * a.B + b) * S + d];
+    else eps = rng_normal_at(a.seed, STREAM_NOISE, a.call, (uint64_t)b * S + d);
+    nxt[d] = msel + eps * sd;                                             // :220-226
+  }
+  float pmax = 0.f;
+#pragma unroll
+  for (int e = 0; e < NENS; ++e) pmax = fmaxf(pmax, sq[e]);
+  a.penalty[b] = sqrtf(pmax);                                             // :246-249 (last state dim dropped)
+  bool done = term_predicate(a.task, nxt, S);
+  if (a.alive && !a.alive[b]) done = true;
+  a.terminal[b] = done ? 1 : 0;
+}
+
+struct DynFinalArgs {
+  const float* r_mu;     // [E][B]
+  const float* penalty;  // [B]
+  float* reward;         // [B]
+  float* raw_reward;     // [B] or null
+  long long B;
+  float coef;            // penalty_coef if (penalty_coef && use_penalty) else 0
+};
+
+__global__ __launch_bounds__(256) void k_dyn_finalize(DynFinalArgs a) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < NENS; ++e) s += a.r_mu[(long long)e * a.B + b];
+  const float raw = s * (1.f / NENS);                                     // reward.mean(0) :236
+  if (a.raw_reward) a.raw_reward[b] = raw;
+  a.reward[b] = (a.coef != 0.f) ? raw - a.coef * a.penalty[b] : raw;       // :261-263
+}
+
+static int launch_dyn_fwd(const float* blob, const MobodyDynLayout& L, const float* obs, const float* act, long long B,
+                          int use_trg, float* mean, hipStream_t st) {
+  static bool once = false;
+  if (!once) {
+    int rc = allow_big_lds(k_dyn_fwd, TILE_LDS_BYTES);
+    if (rc) return rc;
+    once = true;
+  }
+  DynFwdArgs a{blob, L, obs, act, mean, B, use_trg};
+  hipLaunchKernelGGL(k_dyn_fwd, dim3((unsigned)cdiv(B, BM), NENS), dim3(NTHREADS), TILE_LDS_BYTES, st, a);
+  MB_LAUNCH_OK("k_dyn_fwd");
+  return 0;
+}
+
+}  // namespace mobody
+
+using namespace mobody;
+
+extern "C" int mobody_dyn_forward(const float* dyn_blob, int S, int A, const float* obs, const float* act, int64_t B,
+                                  int use_trg, float* mean, void* stream) {
+  MobodyDynLayout L;
+  int rc = mobody_dyn_layout(S, A, &L);
+  if (rc) return rc;
+  MB_REQUIRE(B >= 0, "mobody_dyn_forward: B < 0");
+  if (B == 0) return 0;                      // empty batch: nothing to do (pointers may be null)
+  MB_REQUIRE(dyn_blob && obs && act && mean, "mobody_dyn_forward: null pointer");
+  return launch_dyn_fwd(dyn_blob, L, obs, act, B, use_trg, mean, as_stream(stream));
+}
+
+extern "C" int64_t mobody_dyn_step_workspace(int S, int A, int64_t B) {
+  (void)A;
+  return (int64_t)NENS * B * S + (int64_t)NENS * B;    // ensemble means + per-member reward means
+}
+
+extern "C" int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, const float* obs, const float* act,
+                               int64_t B, const float* noise, const int32_t* elite_idx, const uint8_t* alive,
+                               const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty,
+                               int use_trg, float* next_obs, float* reward, uint8_t* terminal, float* penalty,
+                               float* raw_reward, float* mean_out, float* workspace, void* stream) {
+  MobodyDynLayout L;
+  int rc = mobody_dyn_layout(S, A, &L);
+  if (rc) return rc;
+  MB_REQUIRE(B >= 0, "mobody_dyn_step: B < 0");
+  if (B == 0) return 0;                      // empty batch: nothing to do (pointers may be null)
+  MB_REQUIRE(dyn_blob && obs && act && next_obs && reward && terminal && penalty && workspace, "mobody_dyn_step: null pointer");
+  MB_REQUIRE(task >= MOBODY_TERM_NEVER && task <= MOBODY_TERM_PEN, "mobody_dyn_step: unknown termination id %d", task);
+  MB_REQUIRE(task != MOBODY_TERM_PEN || S > 26, "mobody_dyn_step: pen predicate needs S > 26");
+  MB_REQUIRE(elite_idx != nullptr || (elites != nullptr && n_elites >= 1 && n_elites <= NENS),
+             "mobody_dyn_step: need elite_idx or 1..7 elites");
+  hipStream_t st = as_stream(stream);
+  float* mean = mean_out ? mean_out : workspace;
+  float* r_mu = workspace + (int64_t)NENS * B * S;
+  rc = launch_dyn_fwd(dyn_blob, L, obs, act, B, use_trg, mean, st);
+  if (rc) return rc;
+
+  DynSampleArgs sa{};
+  sa.mean = mean; sa.noise = noise; sa.elite_idx = elite_idx; sa.alive = alive;
+  for (int k = 0; k < NENS; ++k) sa.elites[k] = (elites && k < n_elites) ? elites[k] : 0;
+  sa.n_elites = n_elites; sa.seed = seed; sa.call = call; sa.B = B; sa.S = S; sa.task = task;
+  sa.next_obs = next_obs; sa.penalty = penalty; sa.terminal = terminal;
+  hipLaunchKernelGGL(k_dyn_sample, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, sa);
+  MB_LAUNCH_OK("k_dyn_sample");
+
+  // reward head on [s, a, s'] shared by the 7 members  (mobody_dynamics.py:235)
+  Mlp3FwdArgs m{};
+  m.src[0] = obs; m.ld[0] = S; m.n[0] = S;
+  m.src[1] = act; m.ld[1] = A; m.n[1] = A;
+  m.src[2] = next_obs; m.ld[2] = S; m.n[2] = S;
+  const MobodyLayer &l1 = L.layer[MOBODY_DL_RW1], &l2 = L.layer[MOBODY_DL_RW2], &l3 = L.layer[MOBODY_DL_RW3];
+  m.w1 = dyn_blob + l1.w_off; m.b1 = dyn_blob + l1.b_off; m.sw1 = (long long)l1.Kp * l1.Np; m.sb1 = l1.Np;
+  m.w2 = dyn_blob + l2.w_off; m.b2 = dyn_blob + l2.b_off; m.sw2 = (long long)l2.Kp * l2.Np; m.sb2 = l2.Np;
+  m.w3 = dyn_blob + l3.w_off; m.b3 = dyn_blob + l3.b_off; m.sw3 = (long long)l3.Kp * l3.Np; m.sb3 = l3.Np;
+  m.Kp1 = l1.Kp; m.Np3 = l3.Np; m.nout = 1; m.rows = B;
+  m.out = r_mu; m.out_mstride = B; m.out_ld = 1;
+  m.out_mode = 0; m.max_action = 1.f;
+  rc = launch_mlp3_fwd(m, NENS, ACT_SWISH, st);
+  if (rc) return rc;
+
+  DynFinalArgs fa{r_mu, penalty, reward, raw_reward, B, (penalty_coef != 0.f && use_penalty) ? penalty_coef : 0.f};
+  hipLaunchKernelGGL(k_dyn_finalize, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, fa);
+  MB_LAUNCH_OK("k_dyn_finalize");
+  return 0;
+}

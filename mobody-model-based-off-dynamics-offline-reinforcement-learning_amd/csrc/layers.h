@@ -1,0 +1,50 @@
+// Layer-level device helpers built on tile.h, and the argument block of the generic fused
+// 3-layer MLP forward kernel (in -> 256 -> 256 -> out) used for:
+//   actor / twin-Q / target twin-Q / V     (ReLU;  mobody.py:35-83)
+//   the ensemble reward head               (Swish; mobody_module.py:295-302)
+//   the DARA classifier heads              (ReLU;  mobody.py:11-33)
+#pragma once
+#include "tile.h"
+
+namespace mobody {
+
+// One hidden layer in place on the LDS image: X <- act(X[:, :Kp] * W + b); `extra(row, col, y)` sees every output.
+template <int ACT, class Extra>
+__device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ W, const float* __restrict__ b, int Kp,
+                                           Extra&& extra) {
+  f32x16 acc[2][2];
+  wide_zero(acc);
+  wide_gemm(Xs, W, Kp, acc);
+  __syncthreads();                       // every wave has finished reading the old image
+  wide_foreach(acc, [&](int row, int col, float v) {
+    const float y = activate<ACT>(v + b[col]);
+    Xs[row * LDX + col] = y;
+    extra(row, col, y);
+  });
+  __syncthreads();
+}
+
+struct NoExtra {
+  __device__ __forceinline__ void operator()(int, int, float) const {}
+};
+
+struct Mlp3FwdArgs {
+  const float* src[3];      // concatenated inputs, src[k] is [rows][n[k]] with leading dim ld[k]; unused: n = 0
+  int ld[3], n[3];
+  const float *w1, *b1, *w2, *b2, *w3, *b3;   // member 0
+  long long sw1, sb1, sw2, sb2, sw3, sb3;     // member strides (floats)
+  int Kp1, Np3, nout;
+  long long rows;
+  float* out;               // out[m*out_mstride + row*out_ld + c], c < nout
+  long long out_mstride;
+  int out_ld;
+  float* save_x;            // [rows][Kp1]           (optional, written by member 0)
+  float* save_h1;           // [members][rows][256]  (optional)
+  float* save_h2;
+  int out_mode;             // 0 raw, 1 max_action*tanh
+  float max_action;
+};
+
+int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stream);
+
+}  // namespace mobody

@@ -1,0 +1,35 @@
+// Stand-alone draws from the device generator (used by tests to read back exactly the
+// noise / indices the fused kernels consume, and by the host mirror for replay sampling).
+#include "common.h"
+#include "rng.h"
+
+namespace mobody {
+
+__global__ void k_rng_normal(uint32_t seed, uint32_t sid, uint32_t call, long long n, float* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = rng_normal_at(seed, sid, call, (uint64_t)i);
+}
+__global__ void k_rng_index(uint32_t seed, uint32_t sid, uint32_t call, long long n, uint32_t bound, int32_t* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)rng_index_at(seed, sid, call, (uint64_t)i, bound);
+}
+
+}  // namespace mobody
+using namespace mobody;
+
+extern "C" int mobody_rng_normal(uint32_t seed, uint32_t stream_id, uint32_t call, int64_t n, float* out, void* stream) {
+  MB_REQUIRE(out && n >= 0, "mobody_rng_normal: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_rng_normal, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), seed, stream_id, call, (long long)n, out);
+  MB_LAUNCH_OK("k_rng_normal");
+  return 0;
+}
+
+extern "C" int mobody_rng_index(uint32_t seed, uint32_t stream_id, uint32_t call, int64_t n, uint32_t bound, int32_t* out,
+                                void* stream) {
+  MB_REQUIRE(out && n >= 0 && bound >= 1, "mobody_rng_index: bad argument");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_rng_index, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), seed, stream_id, call, (long long)n, bound, out);
+  MB_LAUNCH_OK("k_rng_index");
+  return 0;
+}

@@ -1,0 +1,48 @@
+// Argument blocks shared by the training translation units (mlp_bwd.hip, train.hip).
+#pragma once
+#include "common.h"
+
+namespace mobody {
+
+struct Mlp3BwdArgs {
+  const float* dz3;        // [members][rows][Np3] (zero in padded columns)
+  const float* h1;         // [members][rows][256] post-ReLU hidden activations saved by the forward
+  const float* h2;
+  const float* wt;         // transposed blob (member 0)
+  long long t_mstride, w3t, w2t, w1t;
+  int Np3, Np1t;
+  long long rows;
+  float* dz2;              // [members][rows][256] or null (not needed when only dx is wanted)
+  float* dz1;
+  float* dbp;              // [tiles][members][512 + Np3] bias-gradient partials: db1 | db2 | db3
+  float* dx;               // [members][rows][dx_n] input gradient columns [dx_c0, dx_c0 + dx_n)  (DX only)
+  int dx_c0, dx_n;
+};
+int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, hipStream_t st);
+
+struct WgradArgs {
+  const float* A; long long a_mstride; int lda, ka;    // A[rows][lda], columns < ka contribute
+  const float* B; long long b_mstride; int ldb, nb;    // B[rows][ldb], columns < nb contribute
+  long long rows, rows_per_wave;
+  float* slabs; long long slab_stride;                 // partial slab s = slabs + s*slab_stride (gradient-blob layout)
+  long long out_off, out_mstride; int out_ld, out_k, out_n;
+};
+int launch_wgrad(WgradArgs a, int members, int nsplit, hipStream_t st);
+
+struct GradReduceArgs {
+  MobodyMlpLayout L;
+  const float* slabs; long long slab_stride; int nsplit;
+  const float* dbp; int ntiles;
+  float* grad;
+};
+int launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);
+
+// split-K factor (workgroups along the row dimension) used for a batch of `rows`
+inline int wgrad_nsplit(long long rows) {
+  long long s = rows / 256;
+  if (s < 1) s = 1;
+  if (s > 16) s = 16;
+  return (int)s;
+}
+
+}  // namespace mobody

@@ -1,0 +1,430 @@
+// MOBODY gradient step: critic (twin-Q TD regression) and actor (Q-scaled policy gradient +
+// Q-weighted behaviour cloning), assembled from the fused MLP forward/backward kernels plus the
+// small row-wise kernels below.  Reference: algo/offline_offline/mobody.py:189-208 (critic),
+// :246-276 (bc_loss), :314-345 (update_policy), :540-578 (order of updates), :183-187 (Polyak).
+//
+// Row-wise kernels are HBM-streaming (a few floats per row); the scalar reductions are
+// single-workgroup and deterministic (no atomics), so N-GPU == 1-GPU to rounding.
+#include <math.h>
+
+#include "common.h"
+#include "layers.h"
+#include "train.h"
+
+namespace mobody {
+
+// ------------------------------------------------------------------------------------------------
+// workspace carving
+// ------------------------------------------------------------------------------------------------
+struct TrainWs {
+  float *pi, *qt, *q, *qb, *xq, *h1q, *h2q, *xa, *h1a, *h2a, *dz3q, *dz2, *dz1, *dz3a, *dxa, *bcw, *dbp, *slabs;
+  long long slab_stride, total;
+  int nsplit, ntiles;
+  MobodyMlpLayout Lq, La;
+};
+
+static int carve(const MobodyTrainDims& d, float* base, TrainWs& w) {
+  int rc = mobody_mlp_layout(d.S + d.A, 1, 2, &w.Lq);
+  if (rc) return rc;
+  rc = mobody_mlp_layout(d.S, d.A, 1, &w.La);
+  if (rc) return rc;
+  const long long N = d.N, Nt = d.Nt;
+  long long off = 0;
+  auto take = [&](long long n) { float* p = base ? base + off : nullptr; off += (n + 3) & ~3LL; return p; };
+  w.pi = take(N * d.A);
+  w.qt = take(2 * N);
+  w.q = take(2 * N);
+  w.qb = take(2 * Nt);
+  w.xq = take(N * w.Lq.Kp1);
+  w.h1q = take(2 * N * HID);
+  w.h2q = take(2 * N * HID);
+  w.xa = take(N * w.La.Kp1);
+  w.h1a = take(N * HID);
+  w.h2a = take(N * HID);
+  w.dz3q = take(2 * N * w.Lq.Np3);
+  w.dz2 = take(2 * N * HID);
+  w.dz1 = take(2 * N * HID);
+  w.dz3a = take(N * w.La.Np3);
+  w.dxa = take(2 * N * d.A);
+  w.bcw = take(Nt > 0 ? Nt : 1);
+  w.ntiles = (int)cdiv(N, BM);
+  w.nsplit = wgrad_nsplit(N);
+  const long long per_q = 2 * HID + w.Lq.Np3, per_a = 2 * HID + w.La.Np3;
+  w.dbp = take((long long)w.ntiles * (2 * per_q > per_a ? 2 * per_q : per_a));
+  w.slab_stride = w.Lq.total_floats > w.La.total_floats ? w.Lq.total_floats : w.La.total_floats;
+  w.slab_stride = (w.slab_stride + 3) & ~3LL;
+  w.slabs = take(w.slab_stride * w.nsplit);
+  w.total = off;
+  return 0;
+}
+
+static int check_dims(const MobodyTrainDims* d, const char* who) {
+  MB_REQUIRE(d != nullptr, "%s: dims is null", who);
+  MB_REQUIRE(d->N >= 1 && d->Nt >= 0 && d->Nt <= d->N, "%s: need 1 <= N and 0 <= Nt <= N (N=%lld Nt=%lld)", who,
+             (long long)d->N, (long long)d->Nt);
+  MB_REQUIRE(d->N_global >= d->N && d->Nt_global >= d->Nt, "%s: global row counts smaller than local", who);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// row-wise kernels
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* sm) {      // blockDim.x multiple of 64, <= 1024
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int k = 0; k < nw; ++k) s += sm[k];       // same order in every thread: deterministic
+  return s;
+}
+
+// y = r + nd*gamma*min(Qt1,Qt2)(s',pi(s'));  dz3[m] = dL/dq_m = 2 (q_m - y) / N_global   (mobody.py:190-207)
+__global__ __launch_bounds__(256) void k_td_prep(const float* qt, const float* q, const float* r, const float* nd,
+                                                 long long N, float gamma, float invNg, int Np3, float* dz3) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N) return;
+  const float y = r[row] + nd[row] * gamma * fminf(qt[row], qt[N + row]);
+  for (int m = 0; m < 2; ++m) {
+    float* o = dz3 + (m * N + row) * Np3;
+    o[0] = 2.f * (q[m * N + row] - y) * invNg;
+    for (int c = 1; c < Np3; ++c) o[c] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_td_loss(const float* qt, const float* q, const float* r, const float* nd,
+                                                  long long N, float gamma, float invNg, float* out) {
+  __shared__ float sm[16];
+  float s = 0.f;
+  for (long long row = threadIdx.x; row < N; row += blockDim.x) {
+    const float y = r[row] + nd[row] * gamma * fminf(qt[row], qt[N + row]);
+    const float d0 = q[row] - y, d1 = q[N + row] - y;
+    s += d0 * d0 + d1 * d1;
+  }
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) out[0] = s * invNg;       // mse(q1,y)+mse(q2,y), local share
+}
+
+// stats[0] = sum_rows |min(Q1,Q2)(s,pi(s))|, stats[1] = sum_{rows<Nt} |min(Q1,Q2)(s_t,a_t)|   (:318, :259)
+__global__ __launch_bounds__(1024) void k_actor_stats(const float* qp, const float* qb, long long N, long long Nt,
+                                                      float* stats) {
+  __shared__ float sm[16];
+  float s0 = 0.f, s1 = 0.f;
+  for (long long row = threadIdx.x; row < N; row += blockDim.x) s0 += fabsf(fminf(qp[row], qp[N + row]));
+  for (long long row = threadIdx.x; row < Nt; row += blockDim.x) s1 += fabsf(fminf(qb[row], qb[Nt + row]));
+  s0 = block_sum(s0, sm);
+  s1 = block_sum(s1, sm);
+  if (threadIdx.x == 0) { stats[0] = s0; stats[1] = s1; }
+}
+
+struct ActorRowArgs {
+  const float *qp, *qb, *stats, *pi, *act, *dxa;
+  float *dz3q, *bcw, *dz3a, *loss_out;
+  long long N, Nt, Ng, Ntg;
+  int A, Np3q, Np3a;
+  MobodyHyper h;
+};
+
+__device__ __forceinline__ float policy_weight(const ActorRowArgs& a) {       // p_w, mobody.py:318 / :283
+  return a.h.scale_q ? a.h.weight / (a.stats[0] / (float)a.Ng) : 1.f;
+}
+__device__ __forceinline__ float bc_weight(const ActorRowArgs& a, long long row) {   // exp_adv, :257-267
+  if (!a.h.q_weighted) return 1.f;
+  const float qb = fminf(a.qb[row], a.qb[a.Nt + row]);
+  const float adv = qb / (a.stats[1] / (float)a.Ntg);
+  return fminf(expf(3.f * adv), 100.f);
+}
+
+// d(-p_w*mean q)/dq_m routed through torch.min's subgradient (ties split 1/2), and the BC weights.
+__global__ __launch_bounds__(256) void k_actor_prep(ActorRowArgs a) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= a.N) return;
+  const float q0 = a.qp[row], q1 = a.qp[a.N + row];
+  const float c = -policy_weight(a) / (float)a.Ng;
+  const float g0 = q0 < q1 ? 1.f : (q0 == q1 ? 0.5f : 0.f);
+  float* o0 = a.dz3q + row * a.Np3q;
+  float* o1 = a.dz3q + (a.N + row) * a.Np3q;
+  o0[0] = c * g0;
+  o1[0] = c * (1.f - g0);
+  for (int k = 1; k < a.Np3q; ++k) { o0[k] = 0.f; o1[k] = 0.f; }
+  if (row < a.Nt) a.bcw[row] = bc_weight(a, row);
+}
+
+// dL/d(pre-tanh) of the actor: Q path (sum of both members' dx) + BC path on the first Nt rows.
+__global__ __launch_bounds__(256) void k_actor_dpi(ActorRowArgs a) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= a.N) return;
+  const float wbc = row < a.Nt ? a.h.bc_coef * 2.f * a.bcw[row] / ((float)a.Ntg * (float)a.A) : 0.f;
+  float* o = a.dz3a + row * a.Np3a;
+  for (int j = 0; j < a.Np3a; ++j) {
+    float v = 0.f;
+    if (j < a.A) {
+      const float p = a.pi[row * a.A + j];
+      float d = a.dxa[row * a.A + j] + a.dxa[(a.N + row) * a.A + j];
+      if (row < a.Nt) d += wbc * (p - a.act[row * a.A + j]);
+      const float t = p / a.h.max_action;
+      v = d * a.h.max_action * (1.f - t * t);                   // d tanh
+    }
+    o[j] = v;
+  }
+}
+
+// loss_out[0] = p_w*mean(-q) + bc_coef*L_BC, loss_out[1] = L_BC   (local shares of the global means)
+__global__ __launch_bounds__(1024) void k_actor_loss(ActorRowArgs a) {
+  __shared__ float sm[16];
+  float s0 = 0.f, s1 = 0.f;
+  for (long long row = threadIdx.x; row < a.N; row += blockDim.x) s0 -= fminf(a.qp[row], a.qp[a.N + row]);
+  for (long long row = threadIdx.x; row < a.Nt; row += blockDim.x) {
+    const float w = a.bcw[row];
+    float e = 0.f;
+    for (int j = 0; j < a.A; ++j) { const float d = a.pi[row * a.A + j] - a.act[row * a.A + j]; e += d * d; }
+    s1 += w * e;
+  }
+  s0 = block_sum(s0, sm);
+  s1 = block_sum(s1, sm);
+  if (threadIdx.x == 0) {
+    const float bc = s1 / ((float)a.Ntg * (float)a.A);
+    a.loss_out[0] = policy_weight(a) * s0 / (float)a.Ng + a.h.bc_coef * bc;
+    a.loss_out[1] = bc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam + Polyak, transposes
+// ------------------------------------------------------------------------------------------------
+// Same op forms as torch's single-tensor Adam: exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2);
+// denom = sqrt(v)/sqrt(bc2) + eps; p.addcdiv_(m, denom, -lr/bc1).  The scalar constants are formed in double
+// on the host and rounded to fp32 once, as torch does when it multiplies a fp32 tensor by a Python float.
+struct AdamConsts { float w1, b2, w2, step_size, bc2_sqrt, eps, tau, one_minus_tau, gscale; };
+
+__global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m, float* v, float* target, long long n,
+                                              AdamConsts c) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const float gj = g[j] * c.gscale;
+  const float m0 = m[j];
+  const float mj = m0 + c.w1 * (gj - m0);
+  const float vj = c.b2 * v[j] + c.w2 * (gj * gj);
+  m[j] = mj; v[j] = vj;
+  const float pj = p[j] - c.step_size * (mj / (sqrtf(vj) / c.bc2_sqrt + c.eps));
+  p[j] = pj;
+  if (target != nullptr) target[j] = c.tau * pj + c.one_minus_tau * target[j];      // update_target :183-187
+}
+
+__global__ __launch_bounds__(256) void k_mlp_transpose(MobodyMlpLayout L, const float* blob, float* bt) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= L.t_total_floats) return;
+  const int m = (int)(j / L.t_member_floats);
+  const long long o = j - (long long)m * L.t_member_floats;
+  const float* src = blob + (long long)m * L.member_floats;
+  float val;
+  if (o < L.w2t) {                               // W3T[n][k] = W3[k][n]
+    const int n = (int)(o / HID), k = (int)(o % HID);
+    val = src[L.w3 + (long long)k * L.Np3 + n];
+  } else if (o < L.w1t) {                        // W2T[n][k] = W2[k][n]
+    const long long oo = o - L.w2t;
+    const int n = (int)(oo / HID), k = (int)(oo % HID);
+    val = src[L.w2 + (long long)k * HID + n];
+  } else {                                       // W1T[n][k] = W1[k][n], zero for k >= Kp1
+    const long long oo = o - L.w1t;
+    const int n = (int)(oo / L.Np1t), k = (int)(oo % L.Np1t);
+    val = k < L.Kp1 ? src[L.w1 + (long long)k * HID + n] : 0.f;
+  }
+  bt[j] = val;
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers to launch the fused MLP pieces on a packed blob
+// ------------------------------------------------------------------------------------------------
+static Mlp3FwdArgs fwd_args(const float* blob, const MobodyMlpLayout& L, const float* s0, int n0, const float* s1, int n1,
+                            long long rows, float* out, int out_mode, float max_action, float* sx, float* sh1,
+                            float* sh2) {
+  Mlp3FwdArgs a{};
+  a.src[0] = s0; a.ld[0] = n0; a.n[0] = n0;
+  a.src[1] = s1; a.ld[1] = n1; a.n[1] = s1 ? n1 : 0;
+  a.w1 = blob + L.w1; a.b1 = blob + L.b1; a.w2 = blob + L.w2; a.b2 = blob + L.b2; a.w3 = blob + L.w3; a.b3 = blob + L.b3;
+  a.sw1 = a.sb1 = a.sw2 = a.sb2 = a.sw3 = a.sb3 = L.member_floats;
+  a.Kp1 = L.Kp1; a.Np3 = L.Np3; a.nout = L.out_dim; a.rows = rows;
+  a.out = out; a.out_mstride = rows * L.out_dim; a.out_ld = L.out_dim;
+  a.save_x = sx; a.save_h1 = sh1; a.save_h2 = sh2;
+  a.out_mode = out_mode; a.max_action = max_action;
+  return a;
+}
+
+// weight gradients of one packed MLP: three split-K GEMMs + the deterministic reduction
+static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h1, const float* h2, const float* dz3,
+                        const float* dz2, const float* dz1, long long rows, const TrainWs& w, float* grad,
+                        hipStream_t st) {
+  const int M = L.members;
+  WgradArgs g{};
+  g.rows = rows; g.slabs = w.slabs; g.slab_stride = w.slab_stride; g.out_mstride = L.member_floats;
+  // dW1 = x^T dz1   (x is shared by the members)
+  g.A = x; g.a_mstride = 0; g.lda = L.Kp1; g.ka = L.Kp1;
+  g.B = dz1; g.b_mstride = rows * HID; g.ldb = HID; g.nb = HID;
+  g.out_off = L.w1; g.out_ld = HID; g.out_k = L.Kp1; g.out_n = HID;
+  int rc = launch_wgrad(g, M, w.nsplit, st);
+  if (rc) return rc;
+  // dW2 = h1^T dz2
+  g.A = h1; g.a_mstride = rows * HID; g.lda = HID; g.ka = HID;
+  g.B = dz2; g.out_off = L.w2; g.out_k = HID;
+  rc = launch_wgrad(g, M, w.nsplit, st);
+  if (rc) return rc;
+  // dW3 = h2^T dz3
+  g.A = h2;
+  g.B = dz3; g.b_mstride = rows * L.Np3; g.ldb = L.Np3; g.nb = L.Np3;
+  g.out_off = L.w3; g.out_ld = L.Np3; g.out_n = L.Np3;
+  rc = launch_wgrad(g, M, w.nsplit, st);
+  if (rc) return rc;
+  GradReduceArgs r{L, w.slabs, w.slab_stride, w.nsplit, w.dbp, w.ntiles, grad};
+  return launch_grad_reduce(r, st);
+}
+
+static Mlp3BwdArgs bwd_args(const MobodyMlpLayout& L, const float* blob_T, const float* dz3, const float* h1,
+                            const float* h2, long long rows, float* dz2, float* dz1, float* dbp) {
+  Mlp3BwdArgs b{};
+  b.dz3 = dz3; b.h1 = h1; b.h2 = h2; b.wt = blob_T; b.t_mstride = L.t_member_floats;
+  b.w3t = L.w3t; b.w2t = L.w2t; b.w1t = L.w1t; b.Np3 = L.Np3; b.Np1t = L.Np1t; b.rows = rows;
+  b.dz2 = dz2; b.dz1 = dz1; b.dbp = dbp;
+  return b;
+}
+
+}  // namespace mobody
+
+using namespace mobody;
+
+extern "C" int64_t mobody_train_workspace(const MobodyTrainDims* d) {
+  if (check_dims(d, "mobody_train_workspace")) return -1;
+  TrainWs w;
+  if (carve(*d, nullptr, w)) return -1;
+  return w.total;
+}
+
+extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
+                                  const float* q_blob, const float* q_blob_T, const float* qtarg_blob,
+                                  const float* state, const float* action, const float* next_state,
+                                  const float* reward, const float* not_done, float* grad_q, float* loss_out,
+                                  float* workspace, void* stream) {
+  int rc = check_dims(d, "mobody_critic_step");
+  if (rc) return rc;
+  MB_REQUIRE(h && actor_blob && q_blob && q_blob_T && qtarg_blob && state && action && next_state && reward && not_done &&
+                 grad_q && loss_out && workspace, "mobody_critic_step: null pointer");
+  TrainWs w;
+  rc = carve(*d, workspace, w);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  const long long N = d->N;
+  const int S = d->S, A = d->A;
+  // a' = pi(s')                                                             (mobody.py:191)
+  rc = launch_mlp3_fwd(fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pi, 1, h->max_action, nullptr, nullptr, nullptr), 1, ACT_RELU, st);
+  if (rc) return rc;
+  // target twin-Q(s', a')                                                    (:192)
+  rc = launch_mlp3_fwd(fwd_args(qtarg_blob, w.Lq, next_state, S, w.pi, A, N, w.qt, 0, 1.f, nullptr, nullptr, nullptr), 2, ACT_RELU, st);
+  if (rc) return rc;
+  // online twin-Q(s, a), activations kept for the backward                   (:196)
+  rc = launch_mlp3_fwd(fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q), 2, ACT_RELU, st);
+  if (rc) return rc;
+  const float invNg = 1.f / (float)d->N_global;
+  hipLaunchKernelGGL(k_td_prep, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, w.qt, w.q, reward, not_done, N, h->gamma, invNg, w.Lq.Np3, w.dz3q);
+  MB_LAUNCH_OK("k_td_prep");
+  hipLaunchKernelGGL(k_td_loss, dim3(1), dim3(1024), 0, st, w.qt, w.q, reward, not_done, N, h->gamma, invNg, loss_out);
+  MB_LAUNCH_OK("k_td_loss");
+  rc = launch_mlp3_bwd(bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp), 2, false, st);
+  if (rc) return rc;
+  return weight_grads(w.Lq, w.xq, w.h1q, w.h2q, w.dz3q, w.dz2, w.dz1, N, w, grad_q, st);
+}
+
+extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
+                                    const float* q_blob, const float* state, const float* action, float* stats,
+                                    float* workspace, void* stream) {
+  int rc = check_dims(d, "mobody_actor_forward");
+  if (rc) return rc;
+  MB_REQUIRE(h && actor_blob && q_blob && state && action && stats && workspace, "mobody_actor_forward: null pointer");
+  TrainWs w;
+  rc = carve(*d, workspace, w);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  const long long N = d->N, Nt = d->Nt;
+  const int S = d->S, A = d->A;
+  // pi(s) on the whole mixed batch (its first Nt rows are pi(s_true), mobody.py:249,315)
+  rc = launch_mlp3_fwd(fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a), 1, ACT_RELU, st);
+  if (rc) return rc;
+  // Q(s, pi(s)) with the freshly updated critic, activations kept for dQ/da   (:316)
+  rc = launch_mlp3_fwd(fwd_args(q_blob, w.Lq, state, S, w.pi, A, N, w.q, 0, 1.f, nullptr, w.h1q, w.h2q), 2, ACT_RELU, st);
+  if (rc) return rc;
+  // Q(s_true, a_true) for the BC weights                                      (:251)
+  rc = launch_mlp3_fwd(fwd_args(q_blob, w.Lq, state, S, action, A, Nt, w.qb, 0, 1.f, nullptr, nullptr, nullptr), 2, ACT_RELU, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_actor_stats, dim3(1), dim3(1024), 0, st, w.q, w.qb, N, Nt, stats);
+  MB_LAUNCH_OK("k_actor_stats");
+  return 0;
+}
+
+extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
+                                     const float* actor_blob_T, const float* q_blob, const float* q_blob_T,
+                                     const float* state, const float* action, const float* stats, float* grad_actor,
+                                     float* loss_out, float* workspace, void* stream) {
+  int rc = check_dims(d, "mobody_actor_backward");
+  if (rc) return rc;
+  MB_REQUIRE(h && actor_blob && actor_blob_T && q_blob && q_blob_T && state && action && stats && grad_actor && loss_out &&
+                 workspace, "mobody_actor_backward: null pointer");
+  TrainWs w;
+  rc = carve(*d, workspace, w);
+  if (rc) return rc;
+  hipStream_t st = as_stream(stream);
+  const long long N = d->N;
+  ActorRowArgs ra{};
+  ra.qp = w.q; ra.qb = w.qb; ra.stats = stats; ra.pi = w.pi; ra.act = action; ra.dxa = w.dxa;
+  ra.dz3q = w.dz3q; ra.bcw = w.bcw; ra.dz3a = w.dz3a; ra.loss_out = loss_out;
+  ra.N = N; ra.Nt = d->Nt; ra.Ng = d->N_global; ra.Ntg = d->Nt_global > 0 ? d->Nt_global : 1;
+  ra.A = d->A; ra.Np3q = w.Lq.Np3; ra.Np3a = w.La.Np3; ra.h = *h;
+  const unsigned gb = (unsigned)cdiv(N, 256);
+  hipLaunchKernelGGL(k_actor_prep, dim3(gb), dim3(256), 0, st, ra);
+  MB_LAUNCH_OK("k_actor_prep");
+  // dq -> d(action) through the frozen twin-Q (parameters get no gradient, mobody.py:555-556)
+  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, nullptr, nullptr, w.dbp);
+  bq.dx = w.dxa; bq.dx_c0 = d->S; bq.dx_n = d->A;
+  rc = launch_mlp3_bwd(bq, 2, true, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_actor_dpi, dim3(gb), dim3(256), 0, st, ra);
+  MB_LAUNCH_OK("k_actor_dpi");
+  hipLaunchKernelGGL(k_actor_loss, dim3(1), dim3(1024), 0, st, ra);
+  MB_LAUNCH_OK("k_actor_loss");
+  rc = launch_mlp3_bwd(bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp), 1, false, st);
+  if (rc) return rc;
+  return weight_grads(w.La, w.xa, w.h1a, w.h2a, w.dz3a, w.dz2, w.dz1, N, w, grad_actor, st);
+}
+
+extern "C" int mobody_mlp_transpose(int in_dim, int out_dim, int members, const float* blob, float* blob_T, void* stream) {
+  MobodyMlpLayout L;
+  int rc = mobody_mlp_layout(in_dim, out_dim, members, &L);
+  if (rc) return rc;
+  MB_REQUIRE(blob && blob_T, "mobody_mlp_transpose: null pointer");
+  hipLaunchKernelGGL(k_mlp_transpose, dim3((unsigned)cdiv(L.t_total_floats, 256)), dim3(256), 0, as_stream(stream), L, blob, blob_T);
+  MB_LAUNCH_OK("k_mlp_transpose");
+  return 0;
+}
+
+extern "C" int mobody_adam_polyak(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad,
+                                  float* m, float* v, float* target, int64_t t, float lr, float tau, float grad_scale,
+                                  void* stream) {
+  MobodyMlpLayout L;
+  int rc = mobody_mlp_layout(in_dim, out_dim, members, &L);
+  if (rc) return rc;
+  MB_REQUIRE(blob && grad && m && v, "mobody_adam_polyak: null pointer");
+  MB_REQUIRE(t >= 1, "mobody_adam_polyak: step t must be >= 1");
+  // torch.optim.Adam scalar bookkeeping in double, as the reference's host code does
+  const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
+  AdamConsts c;
+  c.w1 = (float)(1.0 - 0.9); c.b2 = (float)0.999; c.w2 = (float)(1.0 - 0.999);
+  c.step_size = (float)((double)lr / bc1); c.bc2_sqrt = (float)sqrt(bc2); c.eps = 1e-8f;
+  c.tau = tau; c.one_minus_tau = (float)(1.0 - (double)tau); c.gscale = grad_scale;
+  float* tgt = (target != nullptr && tau >= 0.f) ? target : nullptr;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)cdiv(L.total_floats, 256)), dim3(256), 0, st, blob, grad, m, v, tgt,
+                     (long long)L.total_floats, c);
+  MB_LAUNCH_OK("k_adam");
+  if (blob_T != nullptr) return mobody_mlp_transpose(in_dim, out_dim, members, blob, blob_T, stream);
+  return 0;
+}

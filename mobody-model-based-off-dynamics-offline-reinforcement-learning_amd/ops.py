@@ -1,0 +1,178 @@
+"""Thin torch-tensor front end of the C ABI (allocation + pointer plumbing only).
+
+Every function here enqueues HIP kernels from libmobody_hip.so on torch's current stream;
+none of them computes anything in PyTorch.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, cur_stream, load, ptr
+
+
+def _f32(t, device=None):
+    t = torch.as_tensor(t, dtype=torch.float32)
+    if device is not None:
+        t = t.to(device)
+    return t.contiguous()
+
+
+def rng_normal(seed, stream_id, call, n, device):
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    check(load().mobody_rng_normal(seed, stream_id, call, n, ptr(out), cur_stream()), "mobody_rng_normal")
+    return out
+
+
+def rng_index(seed, stream_id, call, n, bound, device):
+    out = torch.empty(n, dtype=torch.int32, device=device)
+    check(load().mobody_rng_index(seed, stream_id, call, n, bound, ptr(out), cur_stream()), "mobody_rng_index")
+    return out
+
+
+def dyn_forward(blob, S, A, obs, act, use_trg=True):
+    obs, act = _f32(obs), _f32(act)
+    B = obs.shape[0]
+    mean = torch.empty(7, B, S, dtype=torch.float32, device=obs.device)
+    check(load().mobody_dyn_forward(ptr(blob), S, A, ptr(obs), ptr(act), B, int(use_trg), ptr(mean), cur_stream()),
+          "mobody_dyn_forward")
+    return mean
+
+
+def dyn_step(blob, S, A, task_id, obs, act, noise=None, elite_idx=None, alive=None, elites=(0, 1, 2, 3, 4), seed=0,
+             call=0, penalty_coef=0.0, use_penalty=True, use_trg=True, want_mean=False, workspace=None, out=None):
+    """Returns dict(next_obs[B,S], reward[B,1], terminal uint8[B,1], penalty[B,1], raw_reward[B,1], mean?)."""
+    obs, act = _f32(obs), _f32(act)
+    dev, B = obs.device, obs.shape[0]
+    if noise is not None:
+        noise = _f32(noise, dev)
+        assert noise.shape == (7, B, S)
+    if elite_idx is not None:
+        elite_idx = torch.as_tensor(elite_idx).to(device=dev, dtype=torch.int32).contiguous()
+    need = load().mobody_dyn_step_workspace(S, A, B)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 1), dtype=torch.float32, device=dev)
+    o = out or {}
+    nxt = o.get("next_obs", None)
+    if nxt is None:
+        nxt = torch.empty(B, S, dtype=torch.float32, device=dev)
+    rew = o["reward"] if "reward" in o else torch.empty(B, 1, dtype=torch.float32, device=dev)
+    term = o["terminal"] if "terminal" in o else torch.empty(B, 1, dtype=torch.uint8, device=dev)
+    pen = o["penalty"] if "penalty" in o else torch.empty(B, 1, dtype=torch.float32, device=dev)
+    raw = o["raw_reward"] if "raw_reward" in o else torch.empty(B, 1, dtype=torch.float32, device=dev)
+    mean = torch.empty(7, B, S, dtype=torch.float32, device=dev) if want_mean else None
+    el = (C.c_int32 * len(elites))(*[int(e) for e in elites])
+    check(load().mobody_dyn_step(ptr(blob), S, A, task_id, ptr(obs), ptr(act), B, ptr(noise), ptr(elite_idx),
+                                 ptr(alive), el, len(elites), seed, call, float(penalty_coef), int(bool(use_penalty)),
+                                 int(bool(use_trg)), ptr(nxt), ptr(rew), ptr(term), ptr(pen), ptr(raw), ptr(mean),
+                                 ptr(workspace), cur_stream()), "mobody_dyn_step")
+    res = dict(next_obs=nxt, reward=rew, terminal=term, penalty=pen, raw_reward=raw)
+    if want_mean:
+        res["mean"] = mean
+    return res
+
+
+def mlp3_forward(blob, in_dim, out_dim, members, src0, src1=None, out_mode=0, max_action=1.0, save=False):
+    """out[members, rows, out_dim] (+ saved (x, h1, h2) when save=True)."""
+    src0 = _f32(src0)
+    rows, n0 = src0.shape
+    n1 = 0
+    if src1 is not None:
+        src1 = _f32(src1)
+        n1 = src1.shape[1]
+    dev = src0.device
+    out = torch.empty(members, rows, out_dim, dtype=torch.float32, device=dev)
+    sx = sh1 = sh2 = None
+    if save:
+        L = _lib.mlp_layout(in_dim, out_dim, members)
+        sx = torch.empty(rows, L.Kp1, dtype=torch.float32, device=dev)
+        sh1 = torch.empty(members, rows, 256, dtype=torch.float32, device=dev)
+        sh2 = torch.empty(members, rows, 256, dtype=torch.float32, device=dev)
+    check(load().mobody_mlp3_forward(ptr(blob), in_dim, out_dim, members, ptr(src0), n0, ptr(src1), n1, rows, out_mode,
+                                     float(max_action), ptr(out), ptr(sx), ptr(sh1), ptr(sh2), cur_stream()),
+          "mobody_mlp3_forward")
+    return (out, sx, sh1, sh2) if save else out
+
+
+# ------------------------------------------------------------------------------------------------
+# training step
+# ------------------------------------------------------------------------------------------------
+def train_dims(S, A, N, Nt, N_global=None, Nt_global=None):
+    return _lib.MobodyTrainDims(S, A, N, Nt, N if N_global is None else N_global, Nt if Nt_global is None else Nt_global)
+
+
+def hyper(cfg):
+    return _lib.MobodyHyper(float(cfg["gamma"]), float(cfg["tau"]), float(cfg["max_action"]), float(cfg["weight"]),
+                            float(cfg["bc_coef"]), int(bool(cfg["q_weighted"])), int(bool(cfg["scale_Q"])))
+
+
+def train_workspace(dims, device):
+    n = load().mobody_train_workspace(C.byref(dims))
+    if n < 0:
+        raise _lib.MobodyError("mobody_train_workspace: " + load().mobody_last_error().decode())
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def mlp_transpose(blob, in_dim, out_dim, members):
+    L = _lib.mlp_layout(in_dim, out_dim, members)
+    bt = torch.empty(L.t_total_floats, dtype=torch.float32, device=blob.device)
+    check(load().mobody_mlp_transpose(in_dim, out_dim, members, ptr(blob), ptr(bt), cur_stream()), "mobody_mlp_transpose")
+    return bt
+
+
+def critic_step(dims, hyp, actor_blob, q_blob, q_blob_T, qtarg_blob, batch, grad_q, loss_out, ws):
+    s, a, s2, r, nd = batch
+    check(load().mobody_critic_step(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(q_blob), ptr(q_blob_T),
+                                    ptr(qtarg_blob), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(grad_q),
+                                    ptr(loss_out), ptr(ws), cur_stream()), "mobody_critic_step")
+
+
+def actor_forward(dims, hyp, actor_blob, q_blob, state, action, stats, ws):
+    check(load().mobody_actor_forward(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(q_blob), ptr(state),
+                                      ptr(action), ptr(stats), ptr(ws), cur_stream()), "mobody_actor_forward")
+
+
+def actor_backward(dims, hyp, actor_blob, actor_blob_T, q_blob, q_blob_T, state, action, stats, grad_actor, loss_out,
+                   ws):
+    check(load().mobody_actor_backward(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(actor_blob_T), ptr(q_blob),
+                                       ptr(q_blob_T), ptr(state), ptr(action), ptr(stats), ptr(grad_actor),
+                                       ptr(loss_out), ptr(ws), cur_stream()), "mobody_actor_backward")
+
+
+def adam_polyak(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t, lr, tau=-1.0, grad_scale=1.0):
+    check(load().mobody_adam_polyak(in_dim, out_dim, members, ptr(blob), ptr(blob_T), ptr(grad), ptr(m), ptr(v),
+                                    ptr(target), int(t), float(lr), float(tau), float(grad_scale), cur_stream()),
+          "mobody_adam_polyak")
+
+
+# ------------------------------------------------------------------------------------------------
+# replay data movement
+# ------------------------------------------------------------------------------------------------
+def gather_batch(buffers, indices, S, A, out=None):
+    """buffers: list of (state, action, next_state, reward, not_done) device tensors; indices: int32 device
+    tensors. Returns the concatenated minibatch (state[N,S], action[N,A], next_state[N,S], reward[N,1], not_done[N,1])."""
+    n = len(buffers)
+    dev = buffers[0][0].device
+    views = (_lib.MobodyBufferView * n)(*[_lib.MobodyBufferView(*[ptr(t) for t in b]) for b in buffers])
+    idx = [i.to(device=dev, dtype=torch.int32).contiguous() for i in indices]
+    iptr = (C.c_void_p * n)(*[ptr(i) if i.numel() else None for i in idx])
+    cnt = (C.c_int64 * n)(*[i.numel() for i in idx])
+    N = sum(i.numel() for i in idx)
+    if out is None:
+        out = (torch.empty(N, S, device=dev), torch.empty(N, A, device=dev), torch.empty(N, S, device=dev),
+               torch.empty(N, 1, device=dev), torch.empty(N, 1, device=dev))
+    check(load().mobody_gather_batch(views, iptr, cnt, n, S, A, *[ptr(t) for t in out], cur_stream()),
+          "mobody_gather_batch")
+    return out
+
+
+def ring_append(buf, cap, ptr_size, S, A, obs, act, next_obs, reward, terminal, keep=None):
+    """buf = (state, action, next_state, reward, not_done) ring tensors; ptr_size int64[2] device tensor."""
+    M = obs.shape[0]
+    if M == 0:
+        return
+    dev = obs.device
+    scan = torch.empty(M + 1040, dtype=torch.int32, device=dev)
+    check(load().mobody_ring_append(*[ptr(t) for t in buf], cap, ptr(ptr_size), S, A, ptr(obs), ptr(act), ptr(next_obs),
+                                    ptr(reward), ptr(terminal), ptr(keep), M, ptr(scan), cur_stream()),
+          "mobody_ring_append")

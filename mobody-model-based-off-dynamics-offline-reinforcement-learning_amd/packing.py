@@ -1,0 +1,77 @@
+"""Reference state_dict tensors <-> the packed weight blobs the HIP kernels stream.
+
+Plumbing only (torch pad/transposes, run once per load/save): the layouts come from the C
+ABI (`mobody_dyn_layout`, `mobody_mlp_layout`), so there is one source of truth.
+
+  dynamics : `<layer>.weight [E,in,out]`, `<layer>.bias [E,1,out]`  (mobody_module.py:383-389)
+             -> per layer W[E][Kp][Np] (zero padded; only the inference halves of the
+                latent / reward heads), bias[E][Np]
+  MLP      : `network.{0,2,4}.weight [out,in]`, `.bias [out]`        (mobody.py:35-48)
+             -> per member W1[Kp1][256] b1 W2[256][256] b2 W3[256][Np3] b3  (W = weight.T)
+"""
+import torch
+
+from . import _lib
+
+MLP_KEYS = ("network.0", "network.2", "network.4")
+
+
+def pack_dynamics(params, S, A, device):
+    """params: dict name -> array/tensor in the reference layout. Returns a flat fp32 device blob."""
+    L = _lib.dyn_layout(S, A)
+    blob = torch.zeros(L.total_floats, dtype=torch.float32, device=device)
+    for li, name in enumerate(_lib.DL_NAMES):
+        lay = L.layer[li]
+        W = torch.as_tensor(params[name + ".weight"], dtype=torch.float32).to(device)
+        b = torch.as_tensor(params[name + ".bias"], dtype=torch.float32).to(device)
+        E, K, _ = W.shape
+        assert E == L.E and K == lay.in_dim, (name, tuple(W.shape), lay.in_dim)
+        n = lay.out_dim                                    # leading `out_dim` columns = the half inference uses
+        Wp = torch.zeros(E, lay.Kp, lay.Np, dtype=torch.float32, device=device)
+        Wp[:, :K, :n] = W[:, :, :n]
+        bp = torch.zeros(E, lay.Np, dtype=torch.float32, device=device)
+        bp[:, :n] = b[:, 0, :n]
+        blob[lay.w_off:lay.w_off + Wp.numel()] = Wp.reshape(-1)
+        blob[lay.b_off:lay.b_off + bp.numel()] = bp.reshape(-1)
+    return blob
+
+
+def pack_mlp(member_params, in_dim, out_dim, device, prefixes=None):
+    """member_params: list (one per member) of dicts with `network.{0,2,4}.{weight,bias}` keys
+    (nn.Linear layout), or one dict plus `prefixes` (e.g. ['network1.', 'network2.'] for twin-Q)."""
+    if prefixes is not None:
+        member_params = [{k[len(p):]: v for k, v in member_params.items() if k.startswith(p)} for p in prefixes]
+    M = len(member_params)
+    L = _lib.mlp_layout(in_dim, out_dim, M)
+    blob = torch.zeros(L.total_floats, dtype=torch.float32, device=device)
+    for m, p in enumerate(member_params):
+        base = m * L.member_floats
+        g = lambda k: torch.as_tensor(p[k], dtype=torch.float32).to(device)
+        W1, W2, W3 = g("network.0.weight"), g("network.2.weight"), g("network.4.weight")
+        assert W1.shape == (256, in_dim) and W2.shape == (256, 256) and W3.shape == (out_dim, 256), \
+            "packed MLPs are in->256->256->out (hidden_sizes must be 256)"
+        w1 = torch.zeros(L.Kp1, 256, device=device); w1[:in_dim] = W1.t()
+        w3 = torch.zeros(256, L.Np3, device=device); w3[:, :out_dim] = W3.t()
+        b3 = torch.zeros(L.Np3, device=device); b3[:out_dim] = g("network.4.bias")
+        for off, t in ((L.w1, w1), (L.b1, g("network.0.bias")), (L.w2, W2.t().contiguous()),
+                       (L.b2, g("network.2.bias")), (L.w3, w3), (L.b3, b3)):
+            blob[base + off:base + off + t.numel()] = t.reshape(-1)
+    return blob
+
+
+def unpack_mlp(blob, in_dim, out_dim, members):
+    """Inverse of pack_mlp: list of dicts in nn.Linear layout (clones)."""
+    L = _lib.mlp_layout(in_dim, out_dim, members)
+    out = []
+    for m in range(members):
+        base = m * L.member_floats
+        v = lambda off, n: blob[base + off:base + off + n]
+        out.append({
+            "network.0.weight": v(L.w1, L.Kp1 * 256).view(L.Kp1, 256)[:in_dim].t().contiguous(),
+            "network.0.bias": v(L.b1, 256).clone(),
+            "network.2.weight": v(L.w2, 65536).view(256, 256).t().contiguous(),
+            "network.2.bias": v(L.b2, 256).clone(),
+            "network.4.weight": v(L.w3, 256 * L.Np3).view(256, L.Np3)[:, :out_dim].t().contiguous(),
+            "network.4.bias": v(L.b3, L.Np3)[:out_dim].clone(),
+        })
+    return out

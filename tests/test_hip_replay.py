@@ -1,0 +1,68 @@
+"""Device-resident replay gather / ring append vs the reference's golden ReplayBuffer behaviour (bit exact)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_ring_append_matches_reference_add_batch(dev):
+    from mobody_amd import ops
+    g = gu.load("g8_replay")
+    cap, S, A = 50, 5, 2
+    buf = (torch.zeros(cap, S, device=dev), torch.zeros(cap, A, device=dev), torch.zeros(cap, S, device=dev),
+           torch.zeros(cap, 1, device=dev), torch.zeros(cap, 1, device=dev))
+    ps = torch.zeros(2, dtype=torch.int64, device=dev)
+    names = ("state", "action", "next_state", "reward", "not_done")
+    for ci, (M, want_ptr, want_size) in enumerate(g["log"]):
+        f = lambda k: torch.from_numpy(g[f"add{ci}_{k}"]).to(dev).contiguous()
+        ops.ring_append(buf, cap, ps, S, A, f("obss"), f("actions"), f("next_obss"), f("rewards"),
+                        f("terminals").to(torch.uint8).contiguous())
+        assert ps.cpu().tolist() == [int(want_ptr), int(want_size)], ci
+        for t, k in zip(buf, names):
+            assert (t.cpu().numpy() == g[f"after{ci}_{k}"]).all(), (ci, k)
+    # gather == reference sample() rows for the reference's own index draw
+    out = ops.gather_batch([buf], [torch.from_numpy(g["sample_ind"]).to(dev)], S, A)
+    for t, k in zip(out, names):
+        assert (t.cpu().numpy() == g["sample_" + k]).all(), k
+
+
+def test_ring_append_with_filter_and_concat_gather(dev):
+    from mobody_amd import ops
+    rng = np.random.default_rng(0)
+    cap, S, A, M = 3000, 17, 6, 2500
+    buf = tuple(torch.zeros(cap, n, device=dev) for n in (S, A, S, 1, 1))
+    ps = torch.tensor([2000, 2400], dtype=torch.int64, device=dev)
+    obs, act, nxt = (rng.standard_normal((M, n)).astype(np.float32) for n in (S, A, S))
+    rew = rng.standard_normal((M, 1)).astype(np.float32)
+    term = (rng.uniform(size=(M, 1)) > 0.8).astype(np.uint8)
+    keep = (rng.uniform(size=M) > 0.3).astype(np.uint8)
+    td = lambda x: torch.from_numpy(x).to(dev).contiguous()
+    ops.ring_append(buf, cap, ps, S, A, td(obs), td(act), td(nxt), td(rew), td(term), td(keep))
+    from oracle import mobody_oracle as O
+    K = int(keep.sum())
+    segs, ptr, size = O.ring_append_plan(2000, 2400, cap, K)
+    assert ps.cpu().tolist() == [ptr, size]
+    want = np.zeros((cap, S), np.float32)
+    kept = obs[keep.astype(bool)]
+    for dst, src, ln in segs:
+        want[dst:dst + ln] = kept[src:src + ln]
+    got = buf[0].cpu().numpy()
+    for dst, src, ln in segs:
+        assert (got[dst:dst + ln] == want[dst:dst + ln]).all()
+    assert (buf[4].cpu().numpy()[segs[0][0]:segs[0][0] + segs[0][2], 0] == 1.0 - term[keep.astype(bool)][:segs[0][2], 0]).all()
+    # three-way concatenated gather
+    b2 = tuple(td(rng.standard_normal((100, n)).astype(np.float32)) for n in (S, A, S, 1, 1))
+    i1, i2, i3 = rng.integers(0, cap, 33), rng.integers(0, 100, 20), rng.integers(0, cap, 0)
+    out = ops.gather_batch([buf, b2, buf], [td(i1), td(i2), td(i3)], S, A)
+    for k in range(5):
+        want = np.concatenate([buf[k].cpu().numpy()[i1], b2[k].cpu().numpy()[i2]], 0)
+        assert (out[k].cpu().numpy() == want).all()
