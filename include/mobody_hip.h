@@ -115,6 +115,25 @@ int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, const float* 
                     uint8_t* terminal, float* penalty, float* raw_reward, float* mean_out, float* workspace,
                     void* stream);
 
+/* Termination predicate alone: done[B] (uint8) = terminal_fn(next_obs[B][S])  (terminal_funs.py:10-121). */
+int mobody_termination(int task, const float* next_obs, int64_t B, int S, uint8_t* done, void* stream);
+
+/* Bookkeeping of an on-device multi-step rollout (MOBODY.rollout mobody.py:635-653 without host
+ * compaction): keep[b] = alive_in[b] && (!use_filter || penalty[b] <= env_filter);
+ * alive_out[b] = alive_in[b] && !terminal[b].  alive_in == NULL means all alive; alive_out may alias alive_in. */
+int mobody_rollout_mask(const uint8_t* alive_in, const uint8_t* terminal, const float* penalty, float env_filter,
+                        int use_filter, int64_t B, uint8_t* keep, uint8_t* alive_out, void* stream);
+
+/* Replay indices drawn on the device (np.random.randint(0, size, n), utils.py:128, throughput mode):
+ * out[i] = philox(seed, stream_id, call = (uint32)(counter[0] + call_offset))[i] % size[0]-ish
+ * (multiply-high), with `counter` and `size` read from DEVICE int64 words so a captured graph
+ * advances without new kernel arguments.  size[0] must be >= 1. */
+int mobody_sample_indices(uint32_t seed, uint32_t stream_id, const int64_t* counter, int64_t call_offset, int64_t n,
+                          const int64_t* size, int32_t* out, void* stream);
+
+/* counter[0] += inc (device int64) */
+int mobody_counter_add(int64_t* counter, int64_t inc, void* stream);
+
 /* ---- 3-layer MLP forward (ReLU) -------------------------------------------------------- */
 /* x = concat(src0[rows][n0], src1[rows][n1]) (src1 may be NULL), n0+n1 == in_dim.
  * out_mode 0: out[m][rows][out_dim] raw;  1: max_action*tanh(.) (Policy.forward mobody.py:68-72).
@@ -183,6 +202,10 @@ int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const 
  * gradient first (1/world for an all-reduced SUM). */
 int mobody_adam_polyak(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad, float* m,
                        float* v, float* target, int64_t t, float lr, float tau, float grad_scale, void* stream);
+
+/* PAR reward shaping: reward[i] -= coef * mean_d (next_state_true[i][d] - next_state_model[i][d])^2  (mobody.py:428-434) */
+int mobody_par_penalty(const float* next_state_true, const float* next_state_model, float* reward, float coef,
+                       int64_t n, int S, void* stream);
 
 /* (Re)build the transposed blob from a parameter blob (after loading a checkpoint). */
 int mobody_mlp_transpose(int in_dim, int out_dim, int members, const float* blob, float* blob_T, void* stream);

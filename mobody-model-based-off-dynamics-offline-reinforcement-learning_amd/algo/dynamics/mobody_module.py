@@ -1,0 +1,121 @@
+"""Ensemble latent dynamics network -- host-side mirror of `algo/dynamics/mobody_module.py`.
+
+Keeps the reference constructor signature (:50-64), the parameter names/shapes of its state_dict
+(Appendix B of SURVEY.md: `<layer>.weight [7,in,out]`, `.bias [7,1,out]`, `.saved_weight/.saved_bias`,
+`max/min_logvar(_latent)`, `elites`), the elite bookkeeping (`set_elites` :351-353,
+`random_elite_idxs` :355-357) and `inference()/uninference()`.  The forward passes run in the HIP
+library on a packed copy of the weights (`packed()`, refreshed whenever the tensors change).
+Training-time pieces (reparameterisation noise, decoders, weight decay) belong to the dynamics
+pre-training row of SURVEY 8(f) and are not part of this path.
+"""
+import numpy as np
+import torch
+
+from ... import _lib, ops, packing
+
+LATENT = 16
+
+
+class MOBODYModule(object):
+    def __init__(self, obs_dim, action_dim, hidden_dims, num_ensemble=7, num_elites=5, activation=None,
+                 weight_decays=None, with_reward=True, device="cpu", reward_relu=False, config=None):
+        if isinstance(hidden_dims, (list, tuple)):
+            hidden_dims = hidden_dims[0]
+        if int(hidden_dims) != 256 or int(num_ensemble) != 7:
+            raise ValueError("the MI355X kernels are built for hidden_dims=256, num_ensemble=7 (reference defaults)")
+        self.config = config or {}
+        if self.config.get("mopo") or self.config.get("latent_reward"):
+            raise NotImplementedError("mopo / latent_reward ablations are outside the accelerated path")
+        self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)
+        self.num_ensemble, self.num_elites = 7, int(num_elites)
+        self.device = torch.device("cuda" if str(device) == "cpu" and torch.cuda.is_available() else device)
+        self.training = True
+        self._with_reward = 0
+        self.encode_trg_diff = 0
+        self._layout = _lib.dyn_layout(self.obs_dim, self.action_dim)
+        S, A, H = self.obs_dim, self.action_dim, 256
+        dims = dict(zs1=(S, H), zs2=(H, H), zs3=(H, 2 * LATENT), za_src1=(LATENT + A, 32), za_src2=(32, 2 * LATENT),
+                    za_de_src1=(LATENT, 8), za_de_src2=(8, A), za_trg1=(LATENT + A, 32), za_trg2=(32, 2 * LATENT),
+                    za_de_trg1=(LATENT, 8), za_de_trg2=(8, A), transition1=(LATENT, H), transition2=(H, H),
+                    transition3=(H, S), reward_model1=(2 * S + A, H), reward_model2=(H, H), reward_model3=(H, 2))
+        self._p = {}
+        for name, (i, o) in dims.items():                         # EnsembleLinear.__init__ :371-389
+            w = torch.empty(7, i, o, device=self.device)
+            torch.nn.init.trunc_normal_(w, std=1 / (2 * i ** 0.5))
+            self._p[name + ".weight"] = w
+            self._p[name + ".bias"] = torch.zeros(7, 1, o, device=self.device)
+            self._p[name + ".saved_weight"] = w.clone()
+            self._p[name + ".saved_bias"] = torch.zeros(7, 1, o, device=self.device)
+        self._p["max_logvar"] = torch.ones(S, device=self.device) * 0.5
+        self._p["min_logvar"] = torch.ones(S, device=self.device) * -10
+        self._p["max_logvar_latent"] = torch.ones(LATENT, device=self.device) * 20
+        self._p["min_logvar_latent"] = torch.ones(LATENT, device=self.device) * -20
+        self._p["elites"] = torch.arange(self.num_elites, device=self.device)
+        self._blob = None
+
+    # ---- nn.Module-like surface ----
+    @property
+    def elites(self):
+        return self._p["elites"]
+
+    def state_dict(self):
+        return {k: v.detach().clone() for k, v in self._p.items()}
+
+    def load_state_dict(self, sd, strict=True):
+        for k, v in sd.items():
+            if k not in self._p:
+                if strict:
+                    raise KeyError(f"unexpected key {k} in dynamics state_dict")
+                continue
+            t = torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).to(self.device)
+            if k != "elites" and tuple(t.shape) != tuple(self._p[k].shape):
+                raise RuntimeError(f"size mismatch for {k}: {tuple(t.shape)} vs {tuple(self._p[k].shape)}")
+            self._p[k] = t.to(torch.int64 if k == "elites" else torch.float32).contiguous()
+        if strict:
+            missing = [k for k in self._p if k not in sd]
+            if missing:
+                raise KeyError(f"missing keys in dynamics state_dict: {missing[:4]}...")
+        self._blob = None
+
+    def parameters(self):
+        return [v for k, v in self._p.items() if k != "elites"]
+
+    def to(self, device):
+        return self
+
+    def inference(self):
+        self.training = False
+
+    def uninference(self):
+        self.training = True
+
+    def set_elites(self, indexes):
+        assert len(indexes) <= self.num_ensemble and max(indexes) < self.num_ensemble
+        self._p["elites"] = torch.as_tensor(list(indexes), dtype=torch.int64, device=self.device)
+
+    def random_elite_idxs(self, batch_size):
+        return np.random.choice(self.elites.cpu().numpy(), size=batch_size)      # NumPy global RNG, :355-357
+
+    def load_save(self):
+        for k in list(self._p):
+            if k.endswith(".saved_weight"):
+                self._p[k[:-13] + ".weight"] = self._p[k].clone()
+            if k.endswith(".saved_bias"):
+                self._p[k[:-11] + ".bias"] = self._p[k].clone()
+        self._blob = None
+
+    # ---- HIP side ----
+    def packed(self):
+        if self._blob is None:
+            self._blob = packing.pack_dynamics(self._p, self.obs_dim, self.action_dim, self.device)
+        return self._blob
+
+    def _fwd(self, state, action, use_trg):
+        mean = ops.dyn_forward(self.packed(), self.obs_dim, self.action_dim, state, action, use_trg)
+        return mean, None, None        # (mean, zs_mu, zs_logvar): the latent stats are unused by the hot path
+
+    def forward_trg(self, state, action):
+        return self._fwd(state, action, True)
+
+    def forward_src(self, state, action):
+        return self._fwd(state, action, False)

@@ -1,0 +1,320 @@
+"""MOBODY policy -- host-side mirror of `algo/offline_offline/mobody.py` (class MOBODY, :89-657).
+
+Same plugin surface as the reference: `MOBODY(config, device)`, `.train(src_rb, tar_rb, batch_size,
+writer, wandbrun)`, `.select_action(state, policy, cuda=False)`, `.rollout(init_obss, rollout_length,
+use_trg)`, `.save/.load(prefix)`, attributes `.policy .q_funcs .target_q_funcs .dynamics .total_it
+.fake_replay_buffer`.  What differs is where the arithmetic runs: every forward/backward/optimizer
+op is a kernel of libmobody_hip.so working on packed weight blobs that stay resident in HBM; this
+file only orders the calls (the order of mobody.py:347-578) and draws indices.
+
+Data-parallel use (one process per GPU): when `torch.distributed` is initialised with world > 1 the
+per-rank minibatch is `batch_size` rows per buffer, gradients are all-reduced (RCCL) as two flat
+blobs per step and the two batch statistics of the actor loss as one 2-float message, so the
+N-GPU update equals the 1-GPU update on the concatenated batch.
+
+Not implemented on this path yet (raise NotImplementedError): penalty_type='dara' classifier warm-up,
+`advantage=1` (V-function variant), `rollout_from_src=1`.
+"""
+import numpy as np
+import torch
+
+from ... import _lib, ops, packing
+from .. import utils
+
+REFRESH_EVERY = 5000        # mobody.py:441
+REFRESH_SRC, REFRESH_TAR = 50000, 2000    # :442-443
+
+
+class _PackedNet(object):
+    """nn.Module-like handle on a packed 3-layer MLP (actor: 1 member, twin-Q: 2 members)."""
+
+    def __init__(self, in_dim, out_dim, members, prefixes, device, out_mode=0, max_action=1.0, init=True):
+        self.in_dim, self.out_dim, self.members, self.prefixes = in_dim, out_dim, members, prefixes
+        self.device, self.out_mode, self.max_action = device, out_mode, float(max_action)
+        self.layout = _lib.mlp_layout(in_dim, out_dim, members)
+        if init:                                      # nn.Linear default init (kaiming_uniform a=sqrt(5))
+            sd = {}
+            for p in prefixes:
+                for li, (i, o) in zip((0, 2, 4), ((in_dim, 256), (256, 256), (256, out_dim))):
+                    bound = 1.0 / np.sqrt(i)
+                    sd[f"{p}network.{li}.weight"] = torch.empty(o, i).uniform_(-bound, bound)
+                    sd[f"{p}network.{li}.bias"] = torch.empty(o).uniform_(-bound, bound)
+            self.load_state_dict(sd)
+        self.training = True
+
+    def load_state_dict(self, sd):
+        self.blob = packing.pack_mlp({k: v for k, v in sd.items()}, self.in_dim, self.out_dim, self.device,
+                                     prefixes=list(self.prefixes))
+        self.blob_T = ops.mlp_transpose(self.blob, self.in_dim, self.out_dim, self.members)
+
+    def state_dict(self):
+        out = {}
+        for p, m in zip(self.prefixes, packing.unpack_mlp(self.blob, self.in_dim, self.out_dim, self.members)):
+            out.update({p + k: v for k, v in m.items()})
+        return out
+
+    def parameters(self):
+        return list(self.state_dict().values())
+
+    def clone(self):
+        c = _PackedNet(self.in_dim, self.out_dim, self.members, self.prefixes, self.device, self.out_mode,
+                       self.max_action, init=False)
+        c.blob, c.blob_T = self.blob.clone(), self.blob_T.clone()
+        return c
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, device):
+        return self
+
+    def __call__(self, x, x2=None):
+        x = torch.as_tensor(x, dtype=torch.float32).to(self.device)
+        o = ops.mlp3_forward(self.blob, self.in_dim, self.out_dim, self.members, x, x2, self.out_mode, self.max_action)
+        return o[0] if self.members == 1 else tuple(o[m] for m in range(self.members))
+
+
+class _Adam(object):
+    """Flat Adam state for one packed blob; state_dict in torch.optim.Adam's format (mobody.py:584-594)."""
+
+    def __init__(self, net, lr):
+        self.net, self.lr, self.t = net, float(lr), 0
+        self.m, self.v = torch.zeros_like(net.blob), torch.zeros_like(net.blob)
+        self.grad = torch.zeros_like(net.blob)
+
+    def step(self, target=None, tau=-1.0, grad_scale=1.0):
+        self.t += 1
+        n = self.net
+        ops.adam_polyak(n.in_dim, n.out_dim, n.members, n.blob, n.blob_T, self.grad, self.m, self.v,
+                        None if target is None else target.blob, self.t, self.lr, tau, grad_scale)
+
+    def _unpack(self, blob):
+        n = self.net
+        out = []
+        for m in packing.unpack_mlp(blob, n.in_dim, n.out_dim, n.members):
+            out += [m[f"network.{li}.{wb}"] for li in (0, 2, 4) for wb in ("weight", "bias")]
+        return out
+
+    def state_dict(self):
+        ms, vs = self._unpack(self.m), self._unpack(self.v)
+        state = {i: dict(step=torch.tensor(float(self.t)), exp_avg=ms[i], exp_avg_sq=vs[i]) for i in range(len(ms))}
+        if self.t == 0:
+            state = {}
+        group = dict(lr=self.lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, maximize=False,
+                     foreach=None, capturable=False, differentiable=False, fused=None, params=list(range(len(ms))))
+        return dict(state=state, param_groups=[group])
+
+    def load_state_dict(self, sd):
+        n = self.net
+        st = sd["state"]
+        self.lr = float(sd["param_groups"][0]["lr"])
+        if not st:
+            self.t = 0
+            self.m.zero_(); self.v.zero_()
+            return
+        keys = [f"network.{li}.{wb}" for li in (0, 2, 4) for wb in ("weight", "bias")]
+        per = len(keys)
+        for name, dst in (("exp_avg", "m"), ("exp_avg_sq", "v")):
+            members = [{k: st[m * per + j][name] for j, k in enumerate(keys)} for m in range(n.members)]
+            setattr(self, dst, packing.pack_mlp(members, n.in_dim, n.out_dim, n.device))
+        self.t = int(float(st[0]["step"]))
+
+
+class MOBODY(object):
+    def __init__(self, config, device, target_entropy=None):
+        self.config = config
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("MOBODY (MI355X build) needs a GPU device; there is no CPU fallback")
+        if int(config["hidden_sizes"]) != 256:
+            raise ValueError("hidden_sizes must be 256 (the width the kernels are built for)")
+        self.discount, self.tau = config["gamma"], config["tau"]
+        self.update_interval = config["update_interval"]
+        self.penalty_type = config["penalty_type"]
+        S, A = int(config["state_dim"]), int(config["action_dim"])
+        self.S, self.A = S, A
+        self.rng = config.get("rng", "numpy")               # 'numpy' = reference index/elite streams; 'device' = Philox
+        self.seed = int(config.get("seed", 0))
+        self.fake_replay_buffer = utils.ReplayBuffer(S, A, self.device, rng=self.rng, seed=self.seed + 17)
+        self.total_it = 0
+        self.q_funcs = _PackedNet(S + A, 1, 2, ("network1.", "network2."), self.device)
+        self.target_q_funcs = self.q_funcs.clone().eval()                         # deepcopy, mobody.py:116
+        self.policy = _PackedNet(S, A, 1, ("network.",), self.device, out_mode=1, max_action=config["max_action"])
+        self.q_optimizer = _Adam(self.q_funcs, config["critic_lr"])
+        self.policy_optimizer = _Adam(self.policy, config["actor_lr"])
+        self.dynamics = None
+        self._ws, self._ws_key = None, None
+        self._loss = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
+        self._batch, self._batch_key = None, None
+        self.last_losses = None
+
+    # ------------------------------------------------------------------ acting
+    def select_action(self, state, policy, cuda=False):
+        """mobody.py:138-144."""
+        x = state if isinstance(state, torch.Tensor) else torch.as_tensor(np.asarray(state), dtype=torch.float32)
+        action = policy(x.reshape(-1, self.S).to(self.device))
+        return action.squeeze() if cuda else action.squeeze().cpu().numpy()
+
+    # ------------------------------------------------------------------ rollouts
+    def rollout(self, init_obss, rollout_length, use_trg=True):
+        """mobody.py:596-657: returns (dict of tensors, info).  Tensors stay on the device.
+        Quirk Q1 reproduced: `use_trg` reaches step()'s `use_penalty` slot; the target model is always used."""
+        if rollout_length == 0:
+            return None, None
+        obs = torch.as_tensor(init_obss, dtype=torch.float32).to(self.device)
+        keys = ("obss", "next_obss", "actions", "rewards", "terminals", "penalty")
+        out = {k: [] for k in keys}
+        n_tr = 0
+        for _ in range(rollout_length):
+            act = self.policy(obs).reshape(-1, self.A)
+            r = self.dynamics.step_device(obs, act, use_trg)
+            term = r["terminal"].clone()
+            for k, v in zip(keys, (obs, r["next_obs"].clone(), act, r["reward"].clone(), term.to(torch.float32),
+                                   r["penalty"].clone())):
+                out[k].append(v)
+            n_tr += obs.shape[0]
+            alive = (term == 0).flatten()
+            if int(alive.sum()) == 0:                       # host sync, as the reference's np check (:636)
+                break
+            obs = r["next_obs"][alive]
+        res = {k: torch.cat(v, 0) for k, v in out.items()}
+        rew_mean = res["rewards"].mean()
+        if self.config["filter_bad_rollout"]:
+            keep = (res["penalty"] <= self.config["env_filter"]).squeeze(1)
+            res = {k: v[keep] for k, v in res.items()}
+        return res, {"num_transitions": n_tr, "reward_mean": rew_mean}
+
+    def _rollout_into_fake(self, init_obss, rollout_length, use_trg=True):
+        """Same transitions as rollout()+add_batch, without host compaction: rows keep their index, an
+        alive mask replaces the shrinking batch and the penalty filter is fused into the ring append."""
+        if rollout_length == 0:
+            return 0
+        obs = init_obss
+        B = obs.shape[0]
+        alive = None
+        keep = torch.empty(B, dtype=torch.uint8, device=self.device)
+        for _ in range(rollout_length):
+            act = self.policy(obs).reshape(-1, self.A)
+            r = self.dynamics.step_device(obs, act, use_trg, alive=alive)
+            nalive = torch.empty(B, dtype=torch.uint8, device=self.device)
+            ops.rollout_mask(alive, r["terminal"], r["penalty"], self.config["env_filter"],
+                             self.config["filter_bad_rollout"], keep, nalive)
+            fb = self.fake_replay_buffer
+            ops.ring_append(fb._fields(), fb.max_size, fb.ptr_size, self.S, self.A, obs, act, r["next_obs"],
+                            r["reward"], r["terminal"], keep)
+            obs, alive = r["next_obs"], nalive
+        self.fake_replay_buffer._pull()
+        return B * rollout_length
+
+    def _refresh(self, src_rb, tar_rb):
+        """Model-rollout refresh of the fake buffer, mobody.py:441-513."""
+        cfg = self.config
+        s_idx = src_rb.draw_indices(REFRESH_SRC)
+        t_idx = tar_rb.draw_indices(REFRESH_TAR)
+        src = ops.gather_batch([src_rb._fields()], [s_idx], self.S, self.A)
+        tar = ops.gather_batch([tar_rb._fields()], [t_idx], self.S, self.A)
+        if self.rng == "device":
+            self._rollout_into_fake(src[0], cfg["src_rollout_length"])
+            self._rollout_into_fake(tar[0], cfg["trg_rollout_length"])
+        else:
+            tr, _ = self.rollout(src[0], cfg["src_rollout_length"])
+            self.fake_replay_buffer.add_batch(tr)
+            tr, _ = self.rollout(tar[0], cfg["trg_rollout_length"])
+            self.fake_replay_buffer.add_batch(tr)
+        if cfg["use_src_sa_to_get_target_next_state"]:                       # :460-475 (strict '<' filter)
+            r = self.dynamics.step_device(src[0], src[1])
+            keep = (r["penalty"] < cfg["env_filter"]).to(torch.uint8).squeeze(1)
+            self.fake_replay_buffer.add_batch(dict(obss=src[0], next_obss=r["next_obs"], actions=src[1],
+                                                   rewards=r["reward"], terminals=r["terminal"]), keep=keep)
+        if cfg["rollout_from_src"]:
+            raise NotImplementedError("rollout_from_src=1 needs the DARA classifier (not on the accelerated path yet)")
+
+    # ------------------------------------------------------------------ training
+    def _world(self):
+        d = torch.distributed
+        return d.get_world_size() if d.is_available() and d.is_initialized() else 1
+
+    def train(self, src_replay_buffer, tar_replay_buffer, batch_size=128, writer=None, wandbrun=None):
+        """One gradient step, mobody.py:347-578."""
+        cfg = self.config
+        self.total_it += 1
+        self.src_replay_buffer, self.tar_replay_buffer = src_replay_buffer, tar_replay_buffer
+        if self.penalty_type == "dara":
+            raise NotImplementedError("penalty_type='dara' (classifier warm-up, mobody.py:354-381) is not accelerated yet")
+        if cfg["advantage"]:
+            raise NotImplementedError("advantage=1 (V-function variant) is not accelerated yet")
+        S, A = self.S, self.A
+        ns, nt = int(cfg["src_ratio"] * batch_size), int(cfg["trg_ratio"] * batch_size)
+        nf = int(cfg["fake_batch_scale"] * batch_size) if cfg["fake_batch_scale"] != 0 else 0
+        N, Nt = ns + nt + nf, ns + nt
+        if self._batch_key != (N,):
+            dev = self.device
+            self._batch = (torch.empty(N, S, device=dev), torch.empty(N, A, device=dev), torch.empty(N, S, device=dev),
+                           torch.empty(N, 1, device=dev), torch.empty(N, 1, device=dev))
+            self._batch_key = (N,)
+        b = self._batch
+        # src | tar rows (mobody.py:399-400); index draws in the reference's order
+        s_idx = src_replay_buffer.draw_indices(ns)
+        t_idx = tar_replay_buffer.draw_indices(nt)
+        ops.gather_batch([src_replay_buffer._fields(), tar_replay_buffer._fields()], [s_idx, t_idx], S, A,
+                         out=tuple(t[:Nt] for t in b))
+        if self.penalty_type == "par":                                        # :428-434
+            r = self.dynamics.step_device(b[0][:ns], b[1][:ns])
+            ops.par_penalty(b[2][:ns], r["next_obs"], b[3][:ns], cfg["penalty_coef"])
+        if (self.total_it - 1) % REFRESH_EVERY == 0:
+            self._refresh(src_replay_buffer, tar_replay_buffer)
+        if nf > 0:                                                            # :523-529
+            f_idx = self.fake_replay_buffer.draw_indices(nf)
+            ops.gather_batch([self.fake_replay_buffer._fields()], [f_idx], S, A, out=tuple(t[Nt:] for t in b))
+        self._update(b, N, Nt)
+        if writer is not None and self.total_it % 5000 == 0:
+            q_loss, pi_loss, bc_loss = [float(x) for x in self._loss[:3].tolist()]
+            writer.add_scalar("train/q_loss", q_loss, self.total_it)
+            writer.add_scalar("train/policy_loss", pi_loss, self.total_it)
+            writer.add_scalar("train/bc_loss", bc_loss, self.total_it)
+            if wandbrun is not None:
+                wandbrun.log({"train/policy_loss": pi_loss, "train/q_loss": q_loss}, step=self.total_it)
+
+    def _update(self, b, N, Nt):
+        """critic step -> Adam+Polyak -> actor forward -> (stats all-reduce) -> actor backward -> Adam."""
+        cfg = self.config
+        world = self._world()
+        dims = ops.train_dims(self.S, self.A, N, Nt, N * world, Nt * world)
+        if self._ws_key != (N, Nt):
+            self._ws = ops.train_workspace(dims, self.device)
+            self._ws_key = (N, Nt)
+        hyp = ops.hyper(cfg)
+        qo, po = self.q_optimizer, self.policy_optimizer
+        ops.critic_step(dims, hyp, self.policy.blob, self.q_funcs.blob, self.q_funcs.blob_T, self.target_q_funcs.blob,
+                        b, qo.grad, self._loss[0:1], self._ws)
+        if world > 1:
+            torch.distributed.all_reduce(qo.grad)
+        qo.step(target=self.target_q_funcs, tau=self.tau)                       # Adam then update_target (:546-552)
+        ops.actor_forward(dims, hyp, self.policy.blob, self.q_funcs.blob, b[0], b[1], self._stats, self._ws)
+        if world > 1:
+            torch.distributed.all_reduce(self._stats)
+        ops.actor_backward(dims, hyp, self.policy.blob, self.policy.blob_T, self.q_funcs.blob, self.q_funcs.blob_T,
+                           b[0], b[1], self._stats, po.grad, self._loss[1:3], self._ws)
+        if world > 1:
+            torch.distributed.all_reduce(po.grad)
+        po.step()
+
+    def losses(self):
+        """(q_loss, pi_loss, bc_loss) of the last step (forces a device sync)."""
+        return tuple(float(x) for x in self._loss[:3].tolist())
+
+    # ------------------------------------------------------------------ checkpoints (mobody.py:584-594)
+    def save(self, filename):
+        torch.save(self.q_funcs.state_dict(), filename + "_critic")
+        torch.save(self.q_optimizer.state_dict(), filename + "_critic_optimizer")
+        torch.save(self.policy.state_dict(), filename + "_actor")
+        torch.save(self.policy_optimizer.state_dict(), filename + "_actor_optimizer")
+
+    def load(self, filename):
+        ld = lambda s: torch.load(filename + s, map_location="cpu", weights_only=True)
+        self.q_funcs.load_state_dict(ld("_critic"))
+        self.q_optimizer.load_state_dict(ld("_critic_optimizer"))
+        self.policy.load_state_dict(ld("_actor"))
+        self.policy_optimizer.load_state_dict(ld("_actor_optimizer"))

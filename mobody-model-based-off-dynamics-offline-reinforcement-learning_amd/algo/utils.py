@@ -1,0 +1,130 @@
+"""Device-resident ReplayBuffer -- host-side mirror of the reference's `algo/utils.py:13-193`.
+
+Same constructor, attributes (`state action next_state reward not_done size ptr max_size device`)
+and methods (`add add_batch sample sample_all convert_D4RL`), but the SoA storage lives in HBM and
+every row movement is a HIP kernel (gather: csrc/replay.hip k_gather; append: k_ring_scatter), so
+`sample()` costs no host gather and no H2D copy.  `ptr`/`size` are mirrored in a device int64[2]
+word pair (`ptr_size`) that the append kernels update, and cached on the host.
+
+Index draws: `rng='numpy'` (default) consumes `np.random.randint(0, size, n)` exactly like
+utils.py:128 so the index stream for a given NumPy seed is the reference's; `rng='device'` draws
+Philox indices on the GPU (no host work at all).
+"""
+import numpy as np
+import torch
+
+from .. import ops
+
+FIELDS = ("state", "action", "next_state", "reward", "not_done")
+
+
+class ReplayBuffer(object):
+    def __init__(self, state_dim, action_dim, device, max_size=int(1e6), rng="numpy", seed=0):
+        self.max_size = int(max_size)
+        self.state_dim, self.action_dim = int(state_dim), int(action_dim)
+        self.device = torch.device(device)
+        assert self.device.type == "cuda", "the MI355X replay buffer is device resident (no CPU fallback)"
+        z = lambda n: torch.zeros((self.max_size, n), dtype=torch.float32, device=self.device)
+        self.state, self.action, self.next_state = z(state_dim), z(action_dim), z(state_dim)
+        self.reward, self.not_done = z(1), z(1)
+        self.ptr_size = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self._ptr = self._size = 0
+        self.mobile = 0
+        self.rng, self.seed = rng, int(seed)
+        self._draws = 0
+
+    # ---- ptr / size (host cache of the device words) ----
+    @property
+    def ptr(self):
+        return self._ptr
+
+    @ptr.setter
+    def ptr(self, v):
+        self._ptr = int(v)
+        self.ptr_size[0] = self._ptr
+
+    @property
+    def size(self):
+        return self._size
+
+    @size.setter
+    def size(self, v):
+        self._size = int(v)
+        self.ptr_size[1] = self._size
+
+    def _pull(self):
+        self._ptr, self._size = [int(x) for x in self.ptr_size.tolist()]
+
+    def _fields(self):
+        return tuple(getattr(self, f) for f in FIELDS)
+
+    def _to_dev(self, x, cols=None, dtype=torch.float32):
+        t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
+        t = t.to(device=self.device, dtype=dtype)
+        if cols is not None:
+            t = t.reshape(-1, cols)
+        return t.contiguous()
+
+    # ---- writes ----
+    def add(self, state, action, next_state, reward, done):
+        b = dict(obss=self._to_dev(state, self.state_dim), actions=self._to_dev(action, self.action_dim),
+                 next_obss=self._to_dev(next_state, self.state_dim), rewards=self._to_dev(reward, 1),
+                 terminals=self._to_dev(done, 1))
+        self.add_batch(b)
+
+    def add_batch(self, batch, keep=None):
+        """Bulk ring append (utils.py:43-92).  `batch is None` is a no-op like the reference
+        (rollout_length == 0).  `keep` optionally selects rows on the device (fused filter)."""
+        if batch is None:
+            return
+        s = self._to_dev(batch["obss"], self.state_dim)
+        M = s.shape[0]
+        if M == 0:
+            return
+        a = self._to_dev(batch["actions"], self.action_dim)
+        ns = self._to_dev(batch["next_obss"], self.state_dim)
+        r = self._to_dev(batch["rewards"], 1)
+        d = batch["terminals"]
+        d = d if isinstance(d, torch.Tensor) else torch.as_tensor(np.asarray(d))
+        d = (d.to(self.device).reshape(-1, 1) != 0).to(torch.uint8).contiguous()
+        if keep is not None:
+            keep = keep.to(device=self.device).reshape(-1).to(torch.uint8).contiguous()
+        step = 1 << 20                           # kernel limit per call; also bounds the scan workspace
+        for i in range(0, M, step):
+            j = min(M, i + step)
+            if j - i > self.max_size:
+                raise RuntimeError("add_batch: batch overflows the ring twice (shape mismatch in the reference)")
+            ops.ring_append(self._fields(), self.max_size, self.ptr_size, self.state_dim, self.action_dim, s[i:j],
+                            a[i:j], ns[i:j], r[i:j], d[i:j], None if keep is None else keep[i:j])
+        self._pull()
+
+    def convert_D4RL(self, dataset):
+        """Adopt a D4RL-style dict (utils.py:173-193): the buffer becomes exactly the dataset."""
+        self.state = self._to_dev(dataset["observations"], self.state_dim)
+        self.action = self._to_dev(dataset["actions"], self.action_dim)
+        self.next_state = self._to_dev(dataset["next_observations"], self.state_dim)
+        self.reward = self._to_dev(dataset["rewards"], 1)
+        term = torch.as_tensor(np.asarray(dataset["terminals"])).reshape(-1, 1).to(torch.float32)
+        self.not_done = (1.0 - term).to(self.device).contiguous()
+        self.max_size = max(self.max_size, self.state.shape[0])
+        self.size = self.state.shape[0]
+
+    # ---- reads ----
+    def draw_indices(self, batch_size):
+        """int32 device indices in [0, size)."""
+        if self.rng == "numpy":
+            ind = np.random.randint(0, self.size, size=batch_size)            # raises on size == 0 like utils.py:128
+            return torch.from_numpy(ind.astype(np.int32)).to(self.device, non_blocking=True)
+        if self._size <= 0:
+            raise ValueError("low >= high")
+        self._draws += 1
+        return ops.rng_index(self.seed, 3, self._draws, batch_size, self._size, self.device)
+
+    def sample(self, batch_size):
+        idx = self.draw_indices(int(batch_size))
+        return ops.gather_batch([self._fields()], [idx], self.state_dim, self.action_dim)
+
+    def sample_all(self, cuda=True):
+        n = self.size
+        out = tuple(getattr(self, f)[:n] for f in FIELDS)
+        return out if cuda else tuple(t.cpu() for t in out)

@@ -271,3 +271,44 @@ extern "C" int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, co
   MB_LAUNCH_OK("k_dyn_finalize");
   return 0;
 }
+
+// ---- stand-alone predicate / rollout bookkeeping -------------------------------------------------
+namespace mobody {
+__global__ __launch_bounds__(256) void k_termination(int task, const float* next_obs, long long B, int S, uint8_t* done) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) done[b] = term_predicate(task, next_obs + b * S, S) ? 1 : 0;
+}
+__global__ __launch_bounds__(256) void k_rollout_mask(const uint8_t* alive_in, const uint8_t* terminal, const float* penalty,
+                                                      float env_filter, int use_filter, long long B, uint8_t* keep,
+                                                      uint8_t* alive_out) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const bool alive = alive_in ? alive_in[b] != 0 : true;
+  if (keep) keep[b] = (alive && (!use_filter || penalty[b] <= env_filter)) ? 1 : 0;     // mobody.py:648-653
+  if (alive_out) alive_out[b] = (alive && !terminal[b]) ? 1 : 0;                         // :635-639
+}
+}  // namespace mobody
+
+extern "C" int mobody_termination(int task, const float* next_obs, int64_t B, int S, uint8_t* done, void* stream) {
+  MB_REQUIRE(B >= 0 && S >= 1, "mobody_termination: bad sizes");
+  if (B == 0) return 0;
+  MB_REQUIRE(next_obs && done, "mobody_termination: null pointer");
+  MB_REQUIRE(task >= MOBODY_TERM_NEVER && task <= MOBODY_TERM_PEN, "mobody_termination: unknown termination id %d", task);
+  MB_REQUIRE(task != MOBODY_TERM_PEN || S > 26, "mobody_termination: pen predicate needs S > 26");
+  MB_REQUIRE(S >= 2 || task == MOBODY_TERM_NEVER || task == MOBODY_TERM_HALFCHEETAH || task == MOBODY_TERM_ANT || task == MOBODY_TERM_HUMANOID,
+             "mobody_termination: predicate needs S >= 2");
+  hipLaunchKernelGGL(k_termination, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, as_stream(stream), task, next_obs, (long long)B, S, done);
+  MB_LAUNCH_OK("k_termination");
+  return 0;
+}
+
+extern "C" int mobody_rollout_mask(const uint8_t* alive_in, const uint8_t* terminal, const float* penalty, float env_filter,
+                                   int use_filter, int64_t B, uint8_t* keep, uint8_t* alive_out, void* stream) {
+  MB_REQUIRE(B >= 0, "mobody_rollout_mask: B < 0");
+  if (B == 0) return 0;
+  MB_REQUIRE(terminal && penalty, "mobody_rollout_mask: null pointer");
+  hipLaunchKernelGGL(k_rollout_mask, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, as_stream(stream), alive_in, terminal, penalty,
+                     env_filter, use_filter, (long long)B, keep, alive_out);
+  MB_LAUNCH_OK("k_rollout_mask");
+  return 0;
+}

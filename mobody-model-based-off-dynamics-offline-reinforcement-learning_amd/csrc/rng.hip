@@ -33,3 +33,33 @@ extern "C" int mobody_rng_index(uint32_t seed, uint32_t stream_id, uint32_t call
   MB_LAUNCH_OK("k_rng_index");
   return 0;
 }
+
+namespace mobody {
+__global__ void k_sample_indices(uint32_t seed, uint32_t sid, const long long* counter, long long call_offset, long long n,
+                                 const long long* size, int32_t* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t call = (uint32_t)((counter ? counter[0] : 0) + call_offset);
+  const long long sz = size[0];
+  out[i] = (int32_t)rng_index_at(seed, sid, call, (uint64_t)i, (uint32_t)(sz > 0 ? sz : 1));
+}
+__global__ void k_counter_add(long long* c, long long inc) { c[0] += inc; }
+}  // namespace mobody
+
+extern "C" int mobody_sample_indices(uint32_t seed, uint32_t stream_id, const int64_t* counter, int64_t call_offset, int64_t n,
+                                     const int64_t* size, int32_t* out, void* stream) {
+  MB_REQUIRE(n >= 0, "mobody_sample_indices: n < 0");
+  if (n == 0) return 0;
+  MB_REQUIRE(size && out, "mobody_sample_indices: null pointer");
+  hipLaunchKernelGGL(k_sample_indices, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), seed, stream_id,
+                     (const long long*)counter, (long long)call_offset, (long long)n, (const long long*)size, out);
+  MB_LAUNCH_OK("k_sample_indices");
+  return 0;
+}
+
+extern "C" int mobody_counter_add(int64_t* counter, int64_t inc, void* stream) {
+  MB_REQUIRE(counter, "mobody_counter_add: null pointer");
+  hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, as_stream(stream), (long long*)counter, (long long)inc);
+  MB_LAUNCH_OK("k_counter_add");
+  return 0;
+}

@@ -428,3 +428,26 @@ extern "C" int mobody_adam_polyak(int in_dim, int out_dim, int members, float* b
   if (blob_T != nullptr) return mobody_mlp_transpose(in_dim, out_dim, members, blob, blob_T, stream);
   return 0;
 }
+
+// ---- PAR reward penalty: r -= coef * mean_d (s'_true - s'_model)^2   (mobody.py:428-434) ----
+namespace mobody {
+__global__ __launch_bounds__(256) void k_par_penalty(const float* ns_true, const float* ns_model, float* reward, float coef,
+                                                     long long n, int S) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  float s = 0.f;
+  for (int d = 0; d < S; ++d) { const float e = ns_true[row * S + d] - ns_model[row * S + d]; s += e * e; }
+  reward[row] -= coef * (s / (float)S);
+}
+}  // namespace mobody
+
+extern "C" int mobody_par_penalty(const float* next_state_true, const float* next_state_model, float* reward, float coef,
+                                  int64_t n, int S, void* stream) {
+  MB_REQUIRE(n >= 0 && S >= 1, "mobody_par_penalty: bad sizes");
+  if (n == 0) return 0;
+  MB_REQUIRE(next_state_true && next_state_model && reward, "mobody_par_penalty: null pointer");
+  hipLaunchKernelGGL(k_par_penalty, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), next_state_true,
+                     next_state_model, reward, coef, (long long)n, S);
+  MB_LAUNCH_OK("k_par_penalty");
+  return 0;
+}

@@ -176,3 +176,37 @@ def ring_append(buf, cap, ptr_size, S, A, obs, act, next_obs, reward, terminal, 
     check(load().mobody_ring_append(*[ptr(t) for t in buf], cap, ptr(ptr_size), S, A, ptr(obs), ptr(act), ptr(next_obs),
                                     ptr(reward), ptr(terminal), ptr(keep), M, ptr(scan), cur_stream()),
           "mobody_ring_append")
+
+
+# ------------------------------------------------------------------------------------------------
+# small device-side helpers used by the host mirror
+# ------------------------------------------------------------------------------------------------
+def termination(task_id, next_obs):
+    B, S = next_obs.shape
+    done = torch.empty(B, 1, dtype=torch.uint8, device=next_obs.device)
+    check(load().mobody_termination(task_id, ptr(next_obs), B, S, ptr(done), cur_stream()), "mobody_termination")
+    return done
+
+
+def rollout_mask(alive_in, terminal, penalty, env_filter, use_filter, keep, alive_out):
+    B = terminal.shape[0]
+    check(load().mobody_rollout_mask(ptr(alive_in), ptr(terminal), ptr(penalty), float(env_filter), int(bool(use_filter)),
+                                     B, ptr(keep), ptr(alive_out), cur_stream()), "mobody_rollout_mask")
+
+
+def sample_indices(seed, stream_id, counter, call_offset, n, size_dev, out=None):
+    if out is None:
+        out = torch.empty(n, dtype=torch.int32, device=size_dev.device)
+    check(load().mobody_sample_indices(seed, stream_id, ptr(counter), call_offset, n, ptr(size_dev), ptr(out),
+                                       cur_stream()), "mobody_sample_indices")
+    return out
+
+
+def counter_add(counter, inc=1):
+    check(load().mobody_counter_add(ptr(counter), inc, cur_stream()), "mobody_counter_add")
+
+
+def par_penalty(next_state_true, next_state_model, reward, coef):
+    n, S = next_state_true.shape
+    check(load().mobody_par_penalty(ptr(next_state_true), ptr(next_state_model), ptr(reward), float(coef), n, S,
+                                    cur_stream()), "mobody_par_penalty")

@@ -1,0 +1,207 @@
+"""CLI driver -- mirror of the reference's `train_mobody.py` for mode 3 (offline-offline = MOBODY).
+
+Accepts the reference's flags with the same names, types and defaults (train_mobody.py:210-307),
+merges configuration in the same precedence (yaml <- --params JSON <- CLI-derived keys, :407-416,
+:470-531) and runs the same sequence: seed -> build policy via call_algo -> build buffers -> build
+dynamics -> attach -> `policy.train(...)` loop (:927-928).
+
+Simulators (gym / mujoco-py / d4rl) and datasets are not part of this build: `--synthetic 1` (the
+default when gym/d4rl are not importable) fills the replay buffers with synthetic MuJoCo-shaped
+transitions and random-initialised networks and skips simulator evaluation; with
+`--synthetic 0` the script needs d4rl/gym exactly like the reference and a `--dynamics_path` with a
+pretrained `dynamics.pth` (dynamics pre-training is a 'next' row).
+"""
+import argparse
+import json
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import yaml
+
+# (flag, default, type or None for strings / store_true marker)
+_FLAGS = [
+    ("--dir", "./logs", None), ("--policy", "SAC", None), ("--env", "halfcheetah-friction", None),
+    ("--srctype", "medium", None), ("--tartype", "medium", None), ("--shift_level", 0.1, None),
+    ("--mode", 3, int), ("--seed", 0, int), ("--save-model", False, "store_true"),
+    ("--tar_env_interact_interval", 10, int), ("--max_step", int(1e6), int), ("--params", None, None),
+    ("--purely_model_based", 0, int), ("--num_envs", 32, int), ("--eval_freq", 1000, int), ("--dara_eta", 0, float),
+    ("--only_use_trg_transition", 5e4, int), ("--transition_update_freq", 2500, int),
+    ("--transition_update_start", 5e4, int), ("--trg_rollout_batch_size", 5e4, int), ("--trg_rollout_length", 1, int),
+    ("--src_rollout_batch_size", 5e4, int), ("--src_rollout_length", 1, int), ("--model_based_training_steps", 100, int),
+    ("--fake_batch_scale", 0.5, float), ("--dynamics_lr", 1e-3, float), ("--encoder_loss_coef", 1, float),
+    ("--domain_loss_coef", 0.0, float), ("--cycle_loss_coef", 0.3, float), ("--bc_coef", 1.0, float),
+    ("--q_weighted", 1, int), ("--advantage", 0, int), ("--scale_q", 1, int), ("--mobile", 0, int),
+    ("--relu_reward", 0, int), ("--penalize_fake", 0, int), ("--gaussian_dynamics", 0, int),
+    ("--sep_reward_dynamics", 0, int), ("--vae", 0, int), ("--sas_reward", 0, int), ("--inverse", 0, int),
+    ("--inverse_sep_reward_loss", 0, int), ("--latent_reward", 0, int), ("--filter_bad_rollout", 1, int),
+    ("--train_together", 0, int), ("--encode_sa", 0, int), ("--vae_a", 0, int), ("--train_with_src_threshold", 1, float),
+    ("--env_filter", 10, float), ("--use_src_sa_to_get_target_next_state", 1, int), ("--env_penalty_coef", 0.1, float),
+    ("--lcb_penalty_coef", 0, float), ("--rollout_length", 1, int), ("--rollout_from_src", 0, int),
+    ("--rollout_from_src_length", 2, int), ("--trg_ratio", 1, float), ("--src_ratio", 1, float),
+    ("--dynamics_path", None, str), ("--train_dynamics", 0, int), ("--out_dir_remark", "", str),
+    ("--penalty_type", "par", str), ("--penalty_coef", 0.1, float), ("--representation_noise", 0, float),
+    ("--group", None, str), ("--wandb", 1, int), ("--cat", 0, int), ("--no_vae", 0, int), ("--trg_only", 0, int),
+    ("--mopo", 0, int),
+]
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    for flag, default, typ in _FLAGS:
+        if typ == "store_true":
+            p.add_argument(flag, action="store_true")
+        elif typ is None:
+            p.add_argument(flag, default=default)
+        else:
+            p.add_argument(flag, default=default, type=typ)
+    # additions of this build (not in the reference)
+    p.add_argument("--synthetic", default=None, type=int, help="1: synthetic buffers/networks (no gym/d4rl needed)")
+    p.add_argument("--rng", default="numpy", choices=["numpy", "device"], help="index/elite RNG: reference NumPy stream or device Philox")
+    p.add_argument("--src_rows", default=int(1e6), type=int)
+    p.add_argument("--tar_rows", default=5000, type=int)
+    p.add_argument("--log_every", default=1000, type=int)
+    return p
+
+
+def domain_of(env):
+    """train_mobody.py:314-321."""
+    if "halfcheetah" in env or "hopper" in env or "walker2d" in env or env.split("-")[0] == "ant":
+        return "mujoco"
+    if "pen" in env or "relocate" in env or "door" in env or "hammer" in env:
+        return "adroit"
+    if "antmaze" in env:
+        return "antmaze"
+    raise NotImplementedError
+
+
+def load_yaml(domain, policy, env_base):
+    """config/<domain>/<policy>/<env>.yaml next to the script (train_mobody.py:410-411); the four
+    mujoco MOBODY files of the reference are identical except eval_freq, so a built-in copy of the
+    hyper-parameters is used when no config tree is present."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = os.path.join(here, "config", domain, policy, env_base + ".yaml")
+    if os.path.exists(path):
+        with open(path, "r", encoding="utf-8") as f:
+            return yaml.safe_load(f)
+    if policy != "mobody" or domain != "mujoco":
+        raise FileNotFoundError(path)             # same failure as the reference for configs it does not ship
+    return dict(alpha=0.2, batch_size=128, actor_lr=0.0003, critic_lr=0.0003, gamma=0.99, state_dim=17, action_dim=3,
+                hidden_sizes=256, max_action=1, gaussian_noise_std=1.0, eta=0.1, temperature_opt=False, tau=0.005,
+                update_interval=2, expl_noise=0.2, eval_episode=10, eval_freq=2500, start_steps=5000, max_step=500000,
+                device="cuda", save_freq=5000, lam=0.7, temp=3.0, weight=2.5)
+
+
+def build_config(args, state_dim, action_dim, max_action):
+    """yaml <- --params <- CLI keys (train_mobody.py:407-416, 470-531); env dims override the yaml's."""
+    domain = domain_of(args.env)
+    config = load_yaml(domain, args.policy.lower(), args.env.split("-")[0])
+    if args.params is not None:
+        config.update(json.loads(args.params))
+    shift = args.shift_level
+    if domain == "mujoco" and shift not in ("easy", "medium", "hard"):
+        shift = float(shift)
+    a = args
+    config.update({
+        "env_name": a.env, "state_dim": state_dim, "action_dim": action_dim, "max_action": max_action,
+        "tar_env_interact_interval": int(a.tar_env_interact_interval), "max_step": int(a.max_step), "shift_level": shift,
+        "dara_eta": a.dara_eta, "only_use_trg_transition": a.only_use_trg_transition,
+        "transition_update_freq": a.transition_update_freq, "transition_update_start": a.transition_update_start,
+        "trg_rollout_batch_size": int(a.trg_rollout_batch_size), "trg_rollout_length": int(a.trg_rollout_length),
+        "src_rollout_batch_size": int(a.src_rollout_batch_size), "src_rollout_length": int(a.src_rollout_length),
+        "model_based_training_steps": a.model_based_training_steps, "fake_batch_scale": a.fake_batch_scale,
+        "env_penalty_coef": a.env_penalty_coef, "lcb_penalty_coef": a.lcb_penalty_coef,
+        "encoder_loss_coef": a.encoder_loss_coef, "domain_loss_coef": a.domain_loss_coef,
+        "cycle_loss_coef": a.cycle_loss_coef,
+        "use_src_sa_to_get_target_next_state": a.use_src_sa_to_get_target_next_state,
+        "penalty_type": a.penalty_type, "penalty_coef": a.penalty_coef, "rollout_length": a.rollout_length,
+        "penalize_fake": a.penalize_fake, "representation_noise": a.representation_noise, "eval_freq": a.eval_freq,
+        "bc_coef": a.bc_coef, "rollout_from_src": a.rollout_from_src, "rollout_from_src_length": a.rollout_from_src_length,
+        "env_filter": a.env_filter, "trg_ratio": a.trg_ratio, "src_ratio": a.src_ratio, "q_weighted": a.q_weighted,
+        "advantage": a.advantage, "scale_Q": a.scale_q, "inverse_sep_reward_loss": a.inverse_sep_reward_loss,
+        "latent_reward": a.latent_reward, "filter_bad_rollout": a.filter_bad_rollout, "train_together": a.train_together,
+        "train_with_src_threshold": a.train_with_src_threshold, "no_vae": a.no_vae, "trg_only": a.trg_only,
+        "mopo": a.mopo,
+    })
+    config["rng"], config["seed"] = a.rng, a.seed
+    return config
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if "_" in args.env:
+        args.env = args.env.replace("_", "-")
+    if args.mode != 3:
+        raise NotImplementedError("only mode 3 (offline-offline, MOBODY) is built on the MI355X path")
+    from mobody_amd import synthetic
+    from mobody_amd.algo import utils
+    from mobody_amd.algo.call_algo import call_algo
+    from mobody_amd.algo.dynamics.mobody_dynamics import MOBODYEnsembleDynamics
+    from mobody_amd.algo.dynamics.mobody_module import MOBODYModule
+    from mobody_amd.algo.mb_utils.terminal_funs import get_termination_fn
+
+    synthetic_mode = args.synthetic
+    if synthetic_mode is None:
+        try:
+            import d4rl  # noqa: F401
+            import gym  # noqa: F401
+            synthetic_mode = 0
+        except Exception:
+            synthetic_mode = 1
+    if not synthetic_mode:
+        raise NotImplementedError("real-dataset mode needs gym/d4rl/mujoco-py, which this image lacks; use --synthetic 1")
+    state_dim, action_dim, task = synthetic.env_shape(args.env)
+    max_action = 1.0
+    torch.manual_seed(args.seed); np.random.seed(args.seed); random.seed(args.seed)
+    torch.cuda.manual_seed_all(args.seed)
+    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    config = build_config(args, state_dim, action_dim, max_action)
+    env_penalty_coef = 0.0 if args.mobile == 1 else args.env_penalty_coef
+    print("-" * 60 + f"\nPolicy: {args.policy}, Env: {args.env}, Seed: {args.seed}\n" + "-" * 60)
+
+    terminal_fn = get_termination_fn(task)
+    policy = call_algo(args.policy, config, args.mode, device, terminal_fn=terminal_fn)
+    src_rb = utils.ReplayBuffer(state_dim, action_dim, device, rng=args.rng, seed=args.seed + 1)
+    tar_rb = utils.ReplayBuffer(state_dim, action_dim, device, rng=args.rng, seed=args.seed + 2)
+    synthetic.fill_buffer(src_rb, args.src_rows, task, args.seed)
+    synthetic.fill_buffer(tar_rb, args.tar_rows, task, args.seed + 100)
+
+    model = MOBODYModule(obs_dim=state_dim, action_dim=action_dim, hidden_dims=256, num_ensemble=7, num_elites=5,
+                         weight_decays=[2.5e-5, 5e-5, 7.5e-5, 7.5e-5, 1e-4], device=device,
+                         reward_relu=args.relu_reward, config=config)
+    dynamics = MOBODYEnsembleDynamics(config, model, None, None, terminal_fn, penalty_coef=env_penalty_coef,
+                                      rng=args.rng, seed=args.seed + 3)
+    save_dir = None
+    if args.dynamics_path is not None:
+        save_dir = os.path.join(args.dynamics_path, args.env,
+                                f"srcdatatype-{args.srctype}-tardatatype-{args.tartype}-{args.shift_level}")
+    if save_dir is not None and os.path.exists(os.path.join(save_dir, "dynamics.pth")) and args.train_dynamics == 0:
+        dynamics.load(save_dir)
+        print("----------pretrained dynamics loaded----------")
+    else:
+        synthetic.alive_dynamics(model, task)
+        print("synthetic mode: random-initialised ensemble dynamics (no pre-training on this path)")
+    config.update({"dynamics": dynamics})
+    policy.dynamics = dynamics
+
+    outdir = f"{args.dir}/{args.policy}/{args.env}-srcdatatype-{args.srctype}-tardatatype-{args.tartype}-{args.shift_level}/r{args.seed}{args.out_dir_remark}"
+    if args.save_model:
+        os.makedirs(f"{outdir}/models", exist_ok=True)
+    start = time.time()
+    for t in range(int(config["max_step"])):
+        policy.train(src_rb, tar_rb, config["batch_size"], None, None)
+        if (t + 1) % args.log_every == 0:
+            q, pi, bc = policy.losses()
+            dt = time.time() - start
+            print(f"step {t + 1}: q_loss {q:.4f} pi_loss {pi:.4f} bc_loss {bc:.4f}  {args.log_every / dt:.1f} grad-steps/s")
+            start = time.time()
+        if (t + 1) % config["eval_freq"] == 0 and args.save_model:
+            policy.save(f"{outdir}/models/model")
+    torch.cuda.synchronize()
+    return policy
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,226 @@
+"""Host-side mirror of the reference plugin interface (call_algo / MOBODY / dynamics / ReplayBuffer /
+termination fns) driven the way the reference's train_mobody.py drives it, checked against the
+reference's golden vectors and the oracle (GPU box only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import mobody_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-5, atol=1e-5):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a.astype(np.float64), b.astype(np.float64), rtol=rtol, atol=atol)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def make_dynamics(p, S, A, task, dev, cfg, penalty_coef=0.1, rng="numpy", seed=0):
+    from mobody_amd.algo.dynamics.mobody_module import MOBODYModule
+    from mobody_amd.algo.dynamics.mobody_dynamics import MOBODYEnsembleDynamics
+    from mobody_amd.algo.mb_utils.terminal_funs import get_termination_fn
+    m = MOBODYModule(S, A, 256, 7, 5, device=dev, config=cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()}, strict=False)
+    return MOBODYEnsembleDynamics(cfg, m, None, None, get_termination_fn(task), penalty_coef=penalty_coef, rng=rng, seed=seed)
+
+
+def feed(dyn, eps_list):
+    it = iter(eps_list)
+    dyn.noise_fn = lambda shape: torch.from_numpy(next(it))
+
+
+def test_termination_fn_mirror_vs_golden(dev):
+    from mobody_amd.algo.mb_utils.terminal_funs import get_termination_fn
+    g = gu.load("g5_termination")
+    for t in sorted({k.split("::")[0] for k in g if "::" in k}):
+        n = g[t + "::next_obs"]
+        fn = get_termination_fn(t)
+        d = fn(n, np.zeros((len(n), 6), np.float32), n)
+        assert d.shape == (len(n), 1) and d.dtype == bool
+        assert (d == g[t + "::done"]).all(), t
+    with pytest.raises(TypeError):
+        get_termination_fn("reacher-x")
+
+
+def test_call_algo_contract(dev):
+    from mobody_amd.algo.call_algo import call_algo
+    from mobody_amd.algo.offline_offline.mobody import MOBODY
+    cfg = gu.policy_cfg(17, 6)
+    pol = call_algo("MOBODY", cfg, 3, dev, terminal_fn=None)
+    assert isinstance(pol, MOBODY) and pol.total_it == 0 and pol.fake_replay_buffer.size == 0
+    with pytest.raises(KeyError):
+        call_algo("sac", cfg, 3, dev)
+    with pytest.raises(NotImplementedError):
+        call_algo("IQL", cfg, 3, dev)
+    with pytest.raises(KeyError):
+        call_algo("mobody", {k: v for k, v in cfg.items() if k != "gamma"}, 3, dev)
+    # select_action: numpy in, numpy out, squeezed (mobody.py:138-144)
+    a = pol.select_action(np.zeros((5, 17), np.float32), pol.policy)
+    assert isinstance(a, np.ndarray) and a.shape == (5, 6) and np.abs(a).max() <= 1.0
+    a1 = pol.select_action(np.zeros(17, np.float32), pol.policy, cuda=True)
+    assert a1.is_cuda and a1.shape == (6,)
+    # state_dict key names of Appendix B
+    assert sorted(pol.policy.state_dict()) == sorted(f"network.network.{i}.{w}" for i in (0, 2, 4) for w in ("weight", "bias"))
+    assert sorted(pol.q_funcs.state_dict()) == sorted(f"network{j}.network.{i}.{w}" for j in (1, 2) for i in (0, 2, 4) for w in ("weight", "bias"))
+
+
+@pytest.mark.parametrize("tag", ["h1", "h5", "h3_nopen"])
+def test_mirror_rollout_vs_reference_golden(tag, dev):
+    from mobody_amd.algo.offline_offline.mobody import MOBODY
+    g = gu.load(f"g6_rollout_{tag}")
+    S, A = int(g["S"]), int(g["A"])
+    cfg = gu.policy_cfg(S, A, env_filter=float(g["env_filter"]))
+    pol = MOBODY(cfg, dev)
+    pa, _, _ = gu.policy_params(int(g["actor_seed"]), S, A)
+    pol.policy.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
+    pol.dynamics = make_dynamics(gu.dyn_params_for(g), S, A, "walker2d-medium-v2", dev, cfg)
+    n = int(g["n_steps"])
+    feed(pol.dynamics, [g[f"eps{t}"] for t in range(n)])
+    np.random.seed(77)                         # the golden run drew its elite ids from this NumPy state
+    res, info = pol.rollout(torch.from_numpy(g["init"]).to(dev), int(g["H"]), bool(int(g["use_trg"])))
+    assert info["num_transitions"] == int(g["num_transitions"])
+    close(info["reward_mean"], float(g["reward_mean"]))
+    for k in ("obss", "next_obss", "actions", "rewards", "terminals", "penalty"):
+        assert tuple(res[k].shape) == g["out_" + k].shape, k
+        close(res[k], g["out_" + k])
+
+
+class FixedRows:
+    """ReplayBuffer mirror whose index draw is the identity (the golden run used preset rows)."""
+
+    def __init__(self, rows, S, A, dev):
+        from mobody_amd.algo import utils
+        self.rb = utils.ReplayBuffer(S, A, dev, max_size=len(rows[0]))
+        self.rb.convert_D4RL(dict(observations=rows[0], actions=rows[1], next_observations=rows[2],
+                                  rewards=rows[3][:, 0], terminals=1.0 - rows[4][:, 0]))
+        self.rb.draw_indices = lambda n: torch.arange(n, dtype=torch.int32, device=dev)
+        self.calls = []
+
+
+@pytest.mark.parametrize("tag", ["default", "noqw", "noscale", "nofake", "bc05", "par"])
+def test_mirror_train_vs_reference_golden(tag, dev):
+    from mobody_amd.algo.offline_offline.mobody import MOBODY
+    from test_hip_train import params_close
+    g = gu.load(f"g7_train_{tag}")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    cfg = gu.policy_cfg(S, A, **gu.G7_VARIANTS[tag])
+    pol = MOBODY(cfg, dev)
+    pa, pq, _ = gu.policy_params(int(g["seed"]), S, A)
+    pol.policy.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
+    pol.q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+    pol.target_q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+    src = FixedRows(gu.gi.batch(501, 64, S, A), S, A, dev).rb
+    tar = FixedRows(gu.gi.batch(502, 64, S, A), S, A, dev).rb
+    pol.fake_replay_buffer = FixedRows(gu.gi.batch(503, 64, S, A), S, A, dev).rb
+    if tag == "par":
+        pol.dynamics = make_dynamics(gu.dyn_params_for(dict(S=S, A=A, dyn_seed=201, alive_val=0.85, wsum_dyn=g["wsum_dyn"])),
+                                     S, A, "walker2d-medium-v2", dev, cfg)
+        feed(pol.dynamics, [g["par_eps1"], g["par_eps2"]])
+    pol.total_it = 1
+    for step in (1, 2):
+        np.random.seed(9)
+        pol.train(src, tar, bs, None, None)
+        q_loss, pi_loss, bc_loss = pol.losses()
+        close(q_loss, g["q_loss"][step - 1], rtol=1e-5, atol=0)
+        close(pi_loss, g["pi_loss"][step - 1], rtol=5e-5, atol=2e-5)
+        close(bc_loss, g["bc_loss"][step - 1], rtol=5e-5, atol=2e-5)
+        for nm, net in (("q", pol.q_funcs), ("actor", pol.policy), ("qt", pol.target_q_funcs)):
+            for k, v in net.state_dict().items():
+                params_close(gu.sub(v.cpu().numpy()), g[f"s{step}_{nm}_p::{k}"], cfg["critic_lr"])
+    assert pol.total_it == 3
+
+
+def test_device_rollout_into_fake_buffer_matches_oracle(dev):
+    """rng='device': alive-mask rollout + fused filtered append == oracle rollout fed with the device's draws."""
+    from mobody_amd import ops
+    from mobody_amd.algo.offline_offline.mobody import MOBODY
+    S, A, B, H = 17, 6, 300, 3
+    p = gu.gi.dyn_params(201, S, A)
+    p["transition3.bias"][:, 0, 0] += np.float32(0.85)
+    pa, _, _ = gu.policy_params(301, S, A)
+    cfg = gu.policy_cfg(S, A, rng="device", seed=5, src_rollout_length=H, env_filter=0.55)
+    pol = MOBODY(cfg, dev)
+    pol.policy.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
+    pol.dynamics = make_dynamics(p, S, A, "walker2d-medium-v2", dev, cfg, rng="device", seed=11)
+    init = gu.gi.walker_like_obs(np.random.default_rng(4), B, S)
+    pol._rollout_into_fake(torch.from_numpy(init).to(dev), H)
+    fb = pol.fake_replay_buffer
+    # oracle, step by step with the same draws (row b of call t uses noise element b*S+d, elite word b)
+    P, PA = O.to_torch(p), O.to_torch(pa)
+    obs, rows = O.T(init), np.arange(B)
+    want = {k: [] for k in ("s", "a", "s2", "r", "nd")}
+    for t in range(1, H + 1):
+        z = ops.rng_normal(11, 1, t, B * S, dev).cpu().numpy().reshape(B, S)[rows]
+        idx = ops.rng_index(11, 2, t, B, 5, dev).cpu().numpy()[rows]
+        with torch.no_grad():
+            act = O.actor(PA, obs, 1.0)
+            st = O.dyn_step(P, obs, act, np.broadcast_to(z, (7,) + z.shape).copy(), idx, "walker2d-medium-v2",
+                            penalty_coef=0.1)
+        keep = (st["penalty"].numpy()[:, 0] <= cfg["env_filter"])
+        want["s"].append(obs.numpy()[keep]); want["a"].append(act.numpy()[keep]); want["s2"].append(st["next_obs"].numpy()[keep])
+        want["r"].append(st["reward"].numpy()[keep]); want["nd"].append(1.0 - st["terminal"][keep].astype(np.float32))
+        alive = ~st["terminal"][:, 0]
+        obs, rows = st["next_obs"][torch.as_tensor(alive)], rows[alive]
+        if len(rows) == 0:
+            break
+    K = sum(len(x) for x in want["s"])
+    assert 0 < K < B * H and fb.size == K and fb.ptr == K
+    for k, t in (("s", fb.state), ("a", fb.action), ("s2", fb.next_state), ("r", fb.reward), ("nd", fb.not_done)):
+        close(t[:K], np.concatenate(want[k], 0))
+
+
+def test_first_train_call_refreshes_fake_buffer_and_checkpoints_round_trip(dev, tmp_path):
+    from mobody_amd import synthetic
+    from mobody_amd.algo import utils
+    from mobody_amd.algo.call_algo import call_algo
+    from mobody_amd.algo.dynamics.mobody_module import MOBODYModule
+    from mobody_amd.algo.dynamics.mobody_dynamics import MOBODYEnsembleDynamics
+    from mobody_amd.algo.mb_utils.terminal_funs import get_termination_fn
+    S, A, task = 17, 6, "walker2d-medium-v2"
+    cfg = gu.policy_cfg(S, A, rng="device", penalty_type="par", src_rollout_length=2)
+    torch.manual_seed(0)
+    pol = call_algo("mobody", cfg, 3, dev)
+    src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=60000, rng="device", seed=1), 60000, task, 0)
+    tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=5000, rng="device", seed=2), 5000, task, 1)
+    model = synthetic.alive_dynamics(MOBODYModule(S, A, 256, 7, 5, device=dev, config=cfg), task)
+    pol.dynamics = MOBODYEnsembleDynamics(cfg, model, None, None, get_termination_fn(task), penalty_coef=0.1, rng="device")
+    pol.train(src, tar, 128, None, None)
+    n1 = pol.fake_replay_buffer.size
+    # 50000*2 + 2000*1 rollout rows (minus filtered/terminated) + up to 50000 relabelled (s,a) rows
+    assert 50000 < n1 <= 152000
+    for _ in range(3):
+        pol.train(src, tar, 128, None, None)
+    assert pol.total_it == 4 and pol.fake_replay_buffer.size == n1          # no refresh until step 5001
+    assert all(np.isfinite(x) for x in pol.losses())
+    # public step(): reference return types
+    nobs, rew, term, info = pol.dynamics.step(src.state[:10], src.action[:10])
+    assert nobs.shape == (10, S) and rew.shape == (10, 1) and isinstance(term, np.ndarray) and term.dtype == bool
+    assert set(info) == {"samples", "raw_reward", "penalty"} and info["samples"].shape == (7, 10, S)
+    # checkpoints: same four files, loadable back, optimizer step preserved (mobody.py:584-594)
+    prefix = str(tmp_path / "model")
+    pol.save(prefix)
+    for suf in ("_critic", "_critic_optimizer", "_actor", "_actor_optimizer"):
+        assert os.path.exists(prefix + suf)
+    sd = torch.load(prefix + "_critic_optimizer", weights_only=True)
+    assert len(sd["state"]) == 12 and float(sd["state"][0]["step"]) == 4.0
+    pol2 = call_algo("mobody", cfg, 3, dev)
+    pol2.load(prefix)
+    close(pol2.q_funcs.blob, pol.q_funcs.blob, rtol=0, atol=0)
+    close(pol2.policy_optimizer.m, pol.policy_optimizer.m, rtol=0, atol=0)
+    assert pol2.q_optimizer.t == 4
+    # dynamics checkpoint round trip with the reference's key names
+    d = tmp_path / "dyn"; d.mkdir()
+    pol.dynamics.save(str(d))
+    keys = torch.load(str(d / "dynamics.pth"), weights_only=True).keys()
+    assert "zs1.saved_weight" in keys and "elites" in keys and "max_logvar_latent" in keys and len(keys) == 17 * 4 + 5
+    pol.dynamics.load(str(d))
