@@ -87,6 +87,14 @@ int mobody_abi_version(void);
 int mobody_dyn_layout(int S, int A, MobodyDynLayout* out);
 int mobody_mlp_layout(int in_dim, int out_dim, int members, MobodyMlpLayout* out);
 
+/* ---- optional per-kernel timing (measurement only; the one piece of process-global state) ----
+ * Between prof_begin and prof_end every launch of the heavy kernel families is bracketed by a HIP
+ * event pair on its launch stream.  prof_end SYNCHRONISES, then returns the summed milliseconds
+ * and launch counts per family id: 0 mlp3_fwd, 1 mlp3_bwd, 2 wgrad, 3 dyn_fwd (4..7 reserved). */
+#define MOBODY_PROF_IDS 8
+int mobody_prof_begin(int max_events);
+int mobody_prof_end(double* ms_by_id, int64_t* count_by_id, int n_ids);
+
 /* ---- counter based RNG (Philox4x32-10; CPU twin: oracle/mobody_oracle.py rng_*) ---------- */
 int mobody_rng_normal(uint32_t seed, uint32_t stream_id, uint32_t call, int64_t n, float* out, void* stream);
 int mobody_rng_index(uint32_t seed, uint32_t stream_id, uint32_t call, int64_t n, uint32_t bound, int32_t* out,

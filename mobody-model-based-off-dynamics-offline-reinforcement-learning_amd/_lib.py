@@ -54,6 +54,8 @@ PROTOTYPES = {
     "mobody_abi_version": (C.c_int, []),
     "mobody_dyn_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(MobodyDynLayout)]),
     "mobody_mlp_layout": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(MobodyMlpLayout)]),
+    "mobody_prof_begin": (C.c_int, [C.c_int]),
+    "mobody_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(i64), C.c_int]),
     "mobody_rng_normal": (C.c_int, [u32, u32, u32, i64, vp, vp]),
     "mobody_rng_index": (C.c_int, [u32, u32, u32, i64, u32, vp, vp]),
     "mobody_dyn_forward": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp, vp]),

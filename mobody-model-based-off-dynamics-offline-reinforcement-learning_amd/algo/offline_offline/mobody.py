@@ -18,7 +18,7 @@ Not implemented on this path yet (raise NotImplementedError): penalty_type='dara
 import numpy as np
 import torch
 
-from ... import _lib, ops, packing
+from ... import _lib, dp, ops, packing
 from .. import utils
 
 REFRESH_EVERY = 5000        # mobody.py:441
@@ -232,10 +232,6 @@ class MOBODY(object):
             raise NotImplementedError("rollout_from_src=1 needs the DARA classifier (not on the accelerated path yet)")
 
     # ------------------------------------------------------------------ training
-    def _world(self):
-        d = torch.distributed
-        return d.get_world_size() if d.is_available() and d.is_initialized() else 1
-
     def train(self, src_replay_buffer, tar_replay_buffer, batch_size=128, writer=None, wandbrun=None):
         """One gradient step, mobody.py:347-578."""
         cfg = self.config
@@ -278,28 +274,49 @@ class MOBODY(object):
                 wandbrun.log({"train/policy_loss": pi_loss, "train/q_loss": q_loss}, step=self.total_it)
 
     def _update(self, b, N, Nt):
-        """critic step -> Adam+Polyak -> actor forward -> (stats all-reduce) -> actor backward -> Adam."""
-        cfg = self.config
-        world = self._world()
-        dims = ops.train_dims(self.S, self.A, N, Nt, N * world, Nt * world)
+        """critic step -> Adam+Polyak -> actor forward -> (stats all-reduce) -> actor backward -> Adam
+        (exchange protocol: mobody_amd/dp.py)."""
+        d = torch.distributed
+        dp.dp_update(self, b, N, Nt, d if d.is_available() and d.is_initialized() else None)
+
+    # ---- engine interface of dp.dp_update (every method only enqueues HIP kernels) ----
+    def comm_device(self):
+        return self.device
+
+    def _dims(self, N, Nt, Ng, Ntg):
         if self._ws_key != (N, Nt):
-            self._ws = ops.train_workspace(dims, self.device)
+            self._ws = ops.train_workspace(ops.train_dims(self.S, self.A, N, Nt, N, Nt), self.device)
             self._ws_key = (N, Nt)
-        hyp = ops.hyper(cfg)
-        qo, po = self.q_optimizer, self.policy_optimizer
+        return ops.train_dims(self.S, self.A, N, Nt, Ng, Ntg), ops.hyper(self.config)
+
+    def critic_grad(self, b, N, Nt, Ng, Ntg):
+        dims, hyp = self._dims(N, Nt, Ng, Ntg)
         ops.critic_step(dims, hyp, self.policy.blob, self.q_funcs.blob, self.q_funcs.blob_T, self.target_q_funcs.blob,
-                        b, qo.grad, self._loss[0:1], self._ws)
-        if world > 1:
-            torch.distributed.all_reduce(qo.grad)
-        qo.step(target=self.target_q_funcs, tau=self.tau)                       # Adam then update_target (:546-552)
+                        b, self.q_optimizer.grad, self._loss[0:1], self._ws)
+
+    def critic_grad_buffer(self):
+        return self.q_optimizer.grad
+
+    def critic_apply(self):
+        self.q_optimizer.step(target=self.target_q_funcs, tau=self.tau)        # Adam then update_target (:546-552)
+
+    def actor_stats(self, b, N, Nt, Ng, Ntg):
+        dims, hyp = self._dims(N, Nt, Ng, Ntg)
         ops.actor_forward(dims, hyp, self.policy.blob, self.q_funcs.blob, b[0], b[1], self._stats, self._ws)
-        if world > 1:
-            torch.distributed.all_reduce(self._stats)
+
+    def stats_buffer(self):
+        return self._stats
+
+    def actor_grad(self, b, N, Nt, Ng, Ntg):
+        dims, hyp = self._dims(N, Nt, Ng, Ntg)
         ops.actor_backward(dims, hyp, self.policy.blob, self.policy.blob_T, self.q_funcs.blob, self.q_funcs.blob_T,
-                           b[0], b[1], self._stats, po.grad, self._loss[1:3], self._ws)
-        if world > 1:
-            torch.distributed.all_reduce(po.grad)
-        po.step()
+                           b[0], b[1], self._stats, self.policy_optimizer.grad, self._loss[1:3], self._ws)
+
+    def actor_grad_buffer(self):
+        return self.policy_optimizer.grad
+
+    def actor_apply(self):
+        self.policy_optimizer.step()
 
     def losses(self):
         """(q_loss, pi_loss, bc_loss) of the last step (forces a device sync)."""

@@ -34,6 +34,16 @@ inline int allow_big_lds(K kernel, size_t bytes) {
   return 0;
 }
 
+// Optional per-kernel timing (bench.py): when enabled, the launch helpers bracket each launch of a kernel
+// family with a HIP event pair on the launch stream.  Disabled (one branch) in normal operation.
+enum ProfId { PROF_MLP_FWD = 0, PROF_MLP_BWD, PROF_WGRAD, PROF_DYN_FWD, PROF_DYN_TAIL, PROF_ROWWISE, PROF_OPTIM, PROF_REPLAY, PROF_COUNT };
+struct ProfScope {
+  int slot;
+  hipStream_t st;
+  ProfScope(int id, hipStream_t stream);
+  ~ProfScope();
+};
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

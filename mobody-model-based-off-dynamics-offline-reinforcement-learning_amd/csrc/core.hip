@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace mobody {
@@ -21,9 +23,54 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// ---- profiling state (the only process-global state of the library; off by default) ----
+struct ProfEvent { int id; hipEvent_t a, b; };
+static std::vector<ProfEvent>& prof_pool() { static std::vector<ProfEvent> p; return p; }
+static bool g_prof_on = false;
+static size_t g_prof_used = 0;
+
+ProfScope::ProfScope(int id, hipStream_t stream) : slot(-1), st(stream) {
+  if (!g_prof_on || g_prof_used >= prof_pool().size()) return;
+  slot = (int)g_prof_used++;
+  prof_pool()[slot].id = id;
+  (void)hipEventRecord(prof_pool()[slot].a, st);
+}
+ProfScope::~ProfScope() {
+  if (slot >= 0) (void)hipEventRecord(prof_pool()[slot].b, st);
+}
+
 }  // namespace mobody
 
 using namespace mobody;
+
+extern "C" int mobody_prof_begin(int max_events) {
+  MB_REQUIRE(max_events > 0 && max_events <= (1 << 20), "mobody_prof_begin: bad capacity");
+  auto& p = prof_pool();
+  while ((int)p.size() < max_events) {
+    ProfEvent e{};
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return fail(MOBODY_E_LAUNCH, "hipEventCreate failed");
+    p.push_back(e);
+  }
+  g_prof_used = 0;
+  g_prof_on = true;
+  return 0;
+}
+
+extern "C" int mobody_prof_end(double* ms_by_id, int64_t* count_by_id, int n_ids) {
+  g_prof_on = false;
+  MB_REQUIRE(ms_by_id && count_by_id && n_ids >= PROF_COUNT, "mobody_prof_end: need %d slots", (int)PROF_COUNT);
+  for (int i = 0; i < n_ids; ++i) { ms_by_id[i] = 0.0; count_by_id[i] = 0; }
+  for (size_t k = 0; k < g_prof_used; ++k) {
+    ProfEvent& e = prof_pool()[k];
+    if (hipEventSynchronize(e.b) != hipSuccess) return fail(MOBODY_E_LAUNCH, "hipEventSynchronize failed");
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) != hipSuccess) return fail(MOBODY_E_LAUNCH, "hipEventElapsedTime failed");
+    ms_by_id[e.id] += ms;
+    count_by_id[e.id] += 1;
+  }
+  g_prof_used = 0;
+  return 0;
+}
 
 extern "C" const char* mobody_last_error(void) { return last_error().c_str(); }
 extern "C" int mobody_abi_version(void) { return MOBODY_ABI_VERSION; }

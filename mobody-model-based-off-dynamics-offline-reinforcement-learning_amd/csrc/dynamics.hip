@@ -197,6 +197,7 @@ static int launch_dyn_fwd(const float* blob, const MobodyDynLayout& L, const flo
     once = true;
   }
   DynFwdArgs a{blob, L, obs, act, mean, B, use_trg};
+  ProfScope prof(PROF_DYN_FWD, st);
   hipLaunchKernelGGL(k_dyn_fwd, dim3((unsigned)cdiv(B, BM), NENS), dim3(NTHREADS), TILE_LDS_BYTES, st, a);
   MB_LAUNCH_OK("k_dyn_fwd");
   return 0;

@@ -104,6 +104,7 @@ int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, hipStream_t
     once = true;
   }
   dim3 grid((unsigned)cdiv(a.rows, BM), (unsigned)members);
+  ProfScope prof(PROF_MLP_BWD, st);
   if (with_dx) hipLaunchKernelGGL(k_mlp3_bwd<true>, grid, dim3(NTHREADS), TILE_LDS_BYTES, st, a);
   else hipLaunchKernelGGL(k_mlp3_bwd<false>, grid, dim3(NTHREADS), TILE_LDS_BYTES, st, a);
   MB_LAUNCH_OK("k_mlp3_bwd");
@@ -195,6 +196,7 @@ static int launch_wgrad_t(const WgradArgs& a, int members, int nsplit, hipStream
     once = true;
   }
   const int tiles = (int)(cdiv(a.ka, 32 * MT) * cdiv(a.nb, 32 * NT));
+  ProfScope prof(PROF_WGRAD, st);
   hipLaunchKernelGGL((k_wgrad<MT, NT>), dim3(tiles, nsplit, members), dim3(NTHREADS), lds, st, a);
   MB_LAUNCH_OK("k_wgrad");
   return 0;

@@ -65,6 +65,7 @@ int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stre
     once = true;
   }
   dim3 grid((unsigned)cdiv(a.rows, BM), (unsigned)members);
+  ProfScope prof(PROF_MLP_FWD, stream);
   if (act == ACT_SWISH)
     hipLaunchKernelGGL(k_mlp3_fwd<ACT_SWISH>, grid, dim3(NTHREADS), TILE_LDS_BYTES, stream, a);
   else
