@@ -42,9 +42,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   // ---- state encoder: zs = mu-half of zs3(Sw(zs2(Sw(zs1(s)))))   (encode_state :217-225) ----
   tile_load(Xs, 0, a.obs + row0 * S, S, S, 0, rows_here);
   tile_zero_cols(Xs, S, a.L.layer[MOBODY_DL_ZS1].Kp);
-  __syncthreads();
-  wide_layer<ACT_SWISH>(Xs, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, NoExtra{});
-  wide_layer<ACT_SWISH>(Xs, Wp(MOBODY_DL_ZS2), Bp(MOBODY_DL_ZS2), HID, NoExtra{});
+  lds_barrier();
+  wide_layer<ACT_SWISH, 2>(Xs, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, NoExtra{});
+  wide_layer<ACT_SWISH, 2>(Xs, Wp(MOBODY_DL_ZS2), Bp(MOBODY_DL_ZS2), HID, NoExtra{});
 
   // From here to the latent sum every wave works on its own 16 rows: no barriers needed.
   const int i = lane & 15, q = lane >> 4;
@@ -63,7 +63,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   for (int idx = lane; idx < 16 * (Kza - LATENT); idx += 64) {
     const int r = idx / (Kza - LATENT), c = idx - r * (Kza - LATENT);
     const int row = 16 * w + r;
-    Xs[row * LDX + LATENT + c] = (c < A && row < rows_here) ? a.act[(row0 + row) * A + c] : 0.f;
+    const float v = a.act[(row0 + min(row, rows_here - 1)) * A + min(c, A - 1)];      // unconditional, clamped
+    Xs[row * LDX + LATENT + c] = (c < A && row < rows_here) ? v : 0.f;
   }
   f32x4 g[2];
   narrow_gemm<2>(Xs, Wp(la1), Kza, 32, 0, g);
@@ -80,11 +81,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) myrow[r * LDX + i] = zs[0][r] + za[0][r] + b;     // z_ns = zs + za  (:319,327)
   }
-  __syncthreads();
+  lds_barrier();
 
   // ---- transition decoder   (encode_transition :287-293) ----
-  wide_layer<ACT_SWISH>(Xs, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, NoExtra{});
-  wide_layer<ACT_SWISH>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, NoExtra{});
+  wide_layer<ACT_SWISH, 2>(Xs, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, NoExtra{});
+  wide_layer<ACT_SWISH, 2>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, NoExtra{});
   const float* b3 = Bp(MOBODY_DL_TR3);
   float* mean = a.mean + ((long long)e * a.B + row0) * S;
   narrow_layer(Xs, Wp(MOBODY_DL_TR3), HID, a.L.layer[MOBODY_DL_TR3].Np, [&](int row, int col, float v) {

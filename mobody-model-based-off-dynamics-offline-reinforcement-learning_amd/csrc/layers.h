@@ -9,19 +9,21 @@
 namespace mobody {
 
 // One hidden layer in place on the LDS image: X <- act(X[:, :Kp] * W + b); `extra(row, col, y)` sees every output.
-template <int ACT, class Extra>
+template <int ACT, int MT = 2, class Extra>
 __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ W, const float* __restrict__ b, int Kp,
                                            Extra&& extra) {
-  f32x16 acc[2][2];
-  wide_zero(acc);
-  wide_gemm(Xs, W, Kp, acc);
-  __syncthreads();                       // every wave has finished reading the old image
-  wide_foreach(acc, [&](int row, int col, float v) {
-    const float y = activate<ACT>(v + b[col]);
+  f32x16 acc[MT][2];
+  wide_zero<MT>(acc);
+  wide_gemm<MT>(Xs, W, Kp, acc);
+  lds_barrier();                         // every wave has finished reading the old image
+  // the wave's two bias values (columns 64w + 32nt + lane&31) are fetched once, not per accumulator element
+  const float bias0 = b[64 * wave_id() + (lane_id() & 31)], bias1 = b[64 * wave_id() + 32 + (lane_id() & 31)];
+  wide_foreach<MT>(acc, [&](int row, int col, float v) {
+    const float y = activate<ACT>(v + ((col & 32) ? bias1 : bias0));
     Xs[row * LDX + col] = y;
     extra(row, col, y);
   });
-  __syncthreads();
+  lds_barrier();
 }
 
 struct NoExtra {
@@ -46,5 +48,12 @@ struct Mlp3FwdArgs {
 };
 
 int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stream);
+
+// Row-tile height for a launch of `rows` x `members`: 32-row tiles when 64-row tiles would leave the 256 CUs
+// (x up to 2 resident 64-row workgroups) under-filled, 64-row tiles (less weight re-streaming from L2) otherwise.
+inline int pick_tile_rows(long long rows, int members) {
+  const long long blocks64 = ((rows + 63) / 64) * members;
+  return blocks64 >= 1024 ? 64 : 32;
+}
 
 }  // namespace mobody

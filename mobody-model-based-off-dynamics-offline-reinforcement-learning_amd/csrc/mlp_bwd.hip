@@ -18,38 +18,53 @@
 
 namespace mobody {
 
-// per-lane column sums of a wide accumulator after masking; lanes < 32 end up with the full 64-row sums
-// for columns 64w + 32nt + (lane&31), nt = 0,1
-template <class Mask>
-__device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[2][2], float* Xs, float* gdst, int rows_here,
-                                                       Mask&& mask, float (&cs)[2]) {
+// Masked epilogue of a backward wide layer: dz = acc * [h > 0] -> LDS image (+ optional global copy) and the
+// per-column sums of the tile (bias gradient).  The 64 mask values of a lane (saved forward activation h at the
+// lane's accumulator positions) are fetched first with UNCONDITIONAL loads from clamped rows -- a
+// `cond ? load : 0` select makes hipcc branch around every load and drain vmcnt(0) after it (64 serialized HBM
+// round trips per layer, measured 60 % SQ_WAIT_ANY) -- so all 64 are in flight together and cost one round trip.
+// (Holding them across the GEMM instead was tried: 256 VGPRs + 62 spills, slower.)
+// Lanes < 32 end up with the 64-row sums of columns 64w + 32nt + (lane&31), nt = 0,1.
+template <int MT>
+__device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], float* Xs, const float* __restrict__ h,
+                                                       float* gdst, int rows_here, float (&cs)[2]) {
   const int lane = lane_id(), w = wave_id();
-  const int i = lane & 31, h = lane >> 5;
+  const int i = lane & 31, hh = lane >> 5;
+  const float* hp = h + 64 * w + i;
+  float hv[MT][2][16];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh, rows_here - 1);
+      hv[mt][0][r] = hp[row * HID];
+      hv[mt][1][r] = hp[row * HID + 32];
+    }
   cs[0] = cs[1] = 0.f;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
         const int col = 64 * w + 32 * nt + i;
-        const bool valid = row < rows_here;
-        const float dz = (valid && mask(row, col)) ? acc[mt][nt][r] : 0.f;
+        const float dz = (hv[mt][nt][r] > 0.f && row < rows_here) ? acc[mt][nt][r] : 0.f;
         Xs[row * LDX + col] = dz;
-        if (gdst != nullptr && valid) gdst[row * HID + col] = dz;
+        if (gdst != nullptr && row < rows_here) gdst[row * HID + col] = dz;
         cs[nt] += dz;
       }
   cs[0] += __shfl_xor(cs[0], 32);
   cs[1] += __shfl_xor(cs[1], 32);
 }
 
-template <bool DX>
+template <bool DX, int MT>
 __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
+  constexpr int TB = 32 * MT;
   const int m = blockIdx.y;
-  const long long row0 = (long long)blockIdx.x * BM;
-  const int rows_here = (int)min((long long)BM, a.rows - row0);
+  const long long row0 = (long long)blockIdx.x * TB;
+  const int rows_here = (int)min((long long)TB, a.rows - row0);
   const int lane = lane_id(), w = wave_id();
   const float* w3t = a.wt + m * a.t_mstride + a.w3t;
   const float* w2t = a.wt + m * a.t_mstride + a.w2t;
@@ -60,73 +75,88 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   float* dz1 = a.dz1 ? a.dz1 + ((long long)m * a.rows + row0) * HID : nullptr;
   float* dbp = a.dbp + ((long long)blockIdx.x * gridDim.y + m) * (2 * HID + a.Np3);
 
-  tile_load(Xs, 0, a.dz3 + ((long long)m * a.rows + row0) * a.Np3, a.Np3, a.Np3, 0, rows_here);
-  __syncthreads();
+  tile_load(Xs, 0, a.dz3 + ((long long)m * a.rows + row0) * a.Np3, a.Np3, a.Np3, 0, rows_here, TB);
+  lds_barrier();
   if ((int)threadIdx.x < a.Np3) {                 // db3 partial of this tile
     float s = 0.f;
-    for (int r = 0; r < BM; ++r) s += Xs[r * LDX + threadIdx.x];
+    for (int r = 0; r < TB; ++r) s += Xs[r * LDX + threadIdx.x];
     dbp[2 * HID + threadIdx.x] = s;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][2];
   float cs[2];
   // dh2 = dz3 * W3^T ; dz2 = dh2 * [h2 > 0]
-  wide_zero(acc);
-  wide_gemm(Xs, w3t, a.Np3, acc);
-  __syncthreads();
-  wide_mask_store_colsum(acc, Xs, dz2, rows_here, [&](int row, int col) { return h2[row * HID + col] > 0.f; }, cs);
+  wide_zero<MT>(acc);
+  wide_gemm<MT>(Xs, w3t, a.Np3, acc);
+  lds_barrier();
+  wide_mask_store_colsum<MT>(acc, Xs, h2, dz2, rows_here, cs);
   if (lane < 32) { dbp[HID + 64 * w + lane] = cs[0]; dbp[HID + 64 * w + 32 + lane] = cs[1]; }
-  __syncthreads();
+  lds_barrier();
   // dh1 = dz2 * W2^T ; dz1 = dh1 * [h1 > 0]
-  wide_zero(acc);
-  wide_gemm(Xs, w2t, HID, acc);
-  __syncthreads();
-  wide_mask_store_colsum(acc, Xs, dz1, rows_here, [&](int row, int col) { return h1[row * HID + col] > 0.f; }, cs);
+  wide_zero<MT>(acc);
+  wide_gemm<MT>(Xs, w2t, HID, acc);
+  lds_barrier();
+  wide_mask_store_colsum<MT>(acc, Xs, h1, dz1, rows_here, cs);
   if (lane < 32) { dbp[64 * w + lane] = cs[0]; dbp[64 * w + 32 + lane] = cs[1]; }
   if (DX) {
-    __syncthreads();
+    lds_barrier();
     float* dx = a.dx + ((long long)m * a.rows + row0) * a.dx_n;
     narrow_layer(Xs, w1t, HID, a.Np1t, [&](int row, int col, float v) {
       const int c = col - a.dx_c0;
       if (row < rows_here && c >= 0 && c < a.dx_n) dx[row * a.dx_n + c] = v;
-    });
+    }, TB);
   }
 }
 
-int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, hipStream_t st) {
-  if (a.rows <= 0) return 0;
+template <bool DX, int MT>
+static int launch_bwd_t(const Mlp3BwdArgs& a, int members, hipStream_t st) {
+  constexpr size_t lds = (size_t)32 * MT * LDX * sizeof(float);
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_mlp3_bwd<false>, TILE_LDS_BYTES);
-    if (rc) return rc;
-    rc = allow_big_lds(k_mlp3_bwd<true>, TILE_LDS_BYTES);
+    int rc = allow_big_lds(k_mlp3_bwd<DX, MT>, lds);
     if (rc) return rc;
     once = true;
   }
-  dim3 grid((unsigned)cdiv(a.rows, BM), (unsigned)members);
+  dim3 grid((unsigned)cdiv(a.rows, 32 * MT), (unsigned)members);
   ProfScope prof(PROF_MLP_BWD, st);
-  if (with_dx) hipLaunchKernelGGL(k_mlp3_bwd<true>, grid, dim3(NTHREADS), TILE_LDS_BYTES, st, a);
-  else hipLaunchKernelGGL(k_mlp3_bwd<false>, grid, dim3(NTHREADS), TILE_LDS_BYTES, st, a);
+  hipLaunchKernelGGL((k_mlp3_bwd<DX, MT>), grid, dim3(NTHREADS), lds, st, a);
   MB_LAUNCH_OK("k_mlp3_bwd");
   return 0;
 }
 
+// tile_rows (32 or 64) must be the value the caller sized `dbp` / the bias reduction with
+int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, int tile_rows, hipStream_t st) {
+  if (a.rows <= 0) return 0;
+  if (tile_rows == 32) return with_dx ? launch_bwd_t<true, 1>(a, members, st) : launch_bwd_t<false, 1>(a, members, st);
+  return with_dx ? launch_bwd_t<true, 2>(a, members, st) : launch_bwd_t<false, 2>(a, members, st);
+}
+
 // ------------------------------------------------------------------------------------------------
-// weight gradient GEMM
+// weight gradient GEMM (all three layers of one packed MLP in ONE launch)
+//
+//   job 0: dW2  = h1^T dz2      256 x 256      wave tile 64 x 64  (MT = 2)
+//   job 1: dW1  = x^T  dz1      Kp1 x 256      wave tile 32 x 64  (MT = 1)
+//   job 2: dW3^T = dz3^T h2     Np3 x 256      wave tile 32 x 64  (MT = 1), stored transposed into W3's [256][Np3]
+//
+// Rows are the contraction index: lane (i = lane&31, h = lane>>5) reads A[row+h][k0+i] and B[row+h][n0+i], i.e.
+// every wave instruction is two full 128-byte lines, no LDS staging.  Split-K: the 4 waves of a workgroup take
+// 4 consecutive row slices of the same output tile and reduce through LDS; workgroups along the row dimension
+// write separate slabs (deterministic, summed by k_grad_reduce).  Operands of the next 8 rows are prefetched
+// into a second register set while the current 8 rows feed the MFMAs.
+// Block -> work mapping is XCD aware (blocks b and b+8 share an XCD and its L2): all output tiles of one
+// (row slice, member) run on the same XCD back to back, so the slice's activations are fetched from
+// HBM/Infinity Cache once and re-read 4x from that XCD's L2.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NT>
-__global__ __launch_bounds__(NTHREADS, 2) void k_wgrad(WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves][32MT][32NT]
-  constexpr int TK = 32 * MT, TN = 32 * NT;
+template <int MT>
+__device__ __forceinline__ void wgrad_tile(const WgradJob& jb, const WgradArgs& a, int tile, int slice, int m, float* red) {
+  constexpr int NT = 2, TK = 32 * MT, TN = 32 * NT, U = 4;
   const int lane = lane_id(), w = wave_id();
   const int i = lane & 31, h = lane >> 5;
-  const int tiles_n = (a.nb + TN - 1) / TN;
-  const int tk = blockIdx.x / tiles_n, tn = blockIdx.x - tk * tiles_n;
+  const int tk = tile / jb.tiles_n, tn = tile - tk * jb.tiles_n;
   const int k0 = tk * TK, n0 = tn * TN;
-  const int m = blockIdx.z;
-  const float* A = a.A + m * a.a_mstride;
-  const float* B = a.B + m * a.b_mstride;
-  const long long r_begin = ((long long)blockIdx.y * 4 + w) * a.rows_per_wave;
+  const float* A = jb.A + m * jb.a_mstride;
+  const float* B = jb.B + m * jb.b_mstride;
+  const long long r_begin = ((long long)slice * 4 + w) * a.rows_per_wave;
   const long long r_end = min(a.rows, r_begin + a.rows_per_wave);
 
   f32x16 acc[MT][NT];
@@ -137,26 +167,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_wgrad(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
 
-  bool okA[MT], okB[NT];
+  // column masks folded into clamped pointers + 0/1 multipliers (loads stay unconditional and in bounds)
+  const float* pa[MT]; float fa[MT];
+  const float* pb[NT]; float fb[NT];
 #pragma unroll
-  for (int x = 0; x < MT; ++x) okA[x] = (k0 + 32 * x + i) < a.ka;
+  for (int x = 0; x < MT; ++x) { const int c = k0 + 32 * x + i; fa[x] = c < jb.ka ? 1.f : 0.f; pa[x] = A + (c < jb.ka ? c : 0); }
 #pragma unroll
-  for (int y = 0; y < NT; ++y) okB[y] = (n0 + 32 * y + i) < a.nb;
-  const float* pa = A + k0 + i;
-  const float* pb = B + n0 + i;
+  for (int y = 0; y < NT; ++y) { const int c = n0 + 32 * y + i; fb[y] = c < jb.nb ? 1.f : 0.f; pb[y] = B + (c < jb.nb ? c : 0); }
 
-  constexpr int U = 4;     // row pairs per unrolled chunk
-  for (long long rb = r_begin; rb < r_end; rb += 2 * U) {
-    float av[U][MT], bv[U][NT];
+  auto load = [&](long long rb, float (&av)[U][MT], float (&bv)[U][NT]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long row = rb + 2 * u + h;          // lane half h takes the odd row of the pair
-      const bool rv = row < r_end;
+      long long row = rb + 2 * u + h;                 // lane half h takes the odd row of each pair
+      const float rv = row < r_end ? 1.f : 0.f;
+      row = row < r_end ? row : r_begin;              // r_begin < rows whenever this wave has work
 #pragma unroll
-      for (int x = 0; x < MT; ++x) av[u][x] = (rv && okA[x]) ? pa[row * a.lda + 32 * x] : 0.f;
+      for (int x = 0; x < MT; ++x) av[u][x] = pa[x][row * jb.lda] * (fa[x] * rv);
 #pragma unroll
-      for (int y = 0; y < NT; ++y) bv[u][y] = (rv && okB[y]) ? pb[row * a.ldb + 32 * y] : 0.f;
+      for (int y = 0; y < NT; ++y) bv[u][y] = pb[y][row * jb.ldb] * (fb[y] * rv);
     }
+  };
+  auto mma = [&](float (&av)[U][MT], float (&bv)[U][NT]) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -164,9 +195,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_wgrad(WgradArgs a) {
 #pragma unroll
         for (int y = 0; y < NT; ++y)
           acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][x], bv[u][y], acc[x][y], 0, 0, 0);
+  };
+  if (r_begin < r_end) {
+    float a0[U][MT], b0[U][NT], a1[U][MT], b1[U][NT];
+    load(r_begin, a0, b0);
+    for (long long rb = r_begin; rb < r_end; rb += 4 * U) {
+      if (rb + 2 * U < r_end) load(rb + 2 * U, a1, b1);
+      mma(a0, b0);
+      if (rb + 2 * U < r_end) {
+        if (rb + 4 * U < r_end) load(rb + 4 * U, a0, b0);
+        mma(a1, b1);
+      }
+    }
   }
 
-  // ---- reduce the four row slices of this workgroup through LDS ----
+  // ---- reduce the four row slices of this workgroup through LDS, write one slab tile ----
   float* mine = red + w * (TK * TN);
 #pragma unroll
   for (int x = 0; x < MT; ++x)
@@ -178,66 +221,93 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_wgrad(WgradArgs a) {
         mine[kk * TN + 32 * y + i] = acc[x][y][r];
       }
   __syncthreads();
-  float* slab = a.slabs + (long long)blockIdx.y * a.slab_stride + a.out_off + m * a.out_mstride;
+  float* slab = a.slabs + (long long)slice * a.slab_stride + jb.out_off + m * a.out_mstride;
   for (int idx = threadIdx.x; idx < TK * TN; idx += NTHREADS) {
     const int kk = idx / TN, nn = idx - kk * TN;
     const float s = (red[idx] + red[TK * TN + idx]) + (red[2 * TK * TN + idx] + red[3 * TK * TN + idx]);
-    if (k0 + kk < a.out_k && n0 + nn < a.out_n) slab[(long long)(k0 + kk) * a.out_ld + n0 + nn] = s;
+    const int gk = k0 + kk, gn = n0 + nn;
+    if (gk < jb.out_k && gn < jb.out_n) {
+      if (jb.transposed) slab[(long long)gn * jb.out_ld + gk] = s;
+      else if (jb.wide) slab[wide_idx(gk, gn)] = s;
+      else slab[(long long)gk * jb.out_ld + gn] = s;
+    }
   }
 }
 
-template <int MT, int NT>
-static int launch_wgrad_t(const WgradArgs& a, int members, int nsplit, hipStream_t st) {
-  constexpr size_t lds = (size_t)4 * 32 * MT * 32 * NT * sizeof(float);
+__global__ __launch_bounds__(NTHREADS, 2) void k_wgrad(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves][64][64]
+  // XCD-aware decode: blocks with equal (id % 8) share an XCD; consecutive ones walk the tiles of one (slice, member)
+  const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+  const int sm = xcd + 8 * (j / a.tiles_total);
+  const int t = j % a.tiles_total;
+  if (sm >= a.nsplit * a.members) return;
+  const int slice = sm / a.members, m = sm - slice * a.members;
+  if (t < a.job[0].ntiles) wgrad_tile<2>(a.job[0], a, t, slice, m, red);
+  else if (t < a.job[0].ntiles + a.job[1].ntiles) wgrad_tile<1>(a.job[1], a, t - a.job[0].ntiles, slice, m, red);
+  else wgrad_tile<1>(a.job[2], a, t - a.job[0].ntiles - a.job[1].ntiles, slice, m, red);
+}
+
+int launch_wgrad(WgradArgs a, hipStream_t st) {
+  if (a.rows <= 0) return 0;
+  constexpr size_t lds = (size_t)4 * 64 * 64 * sizeof(float);
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_wgrad<MT, NT>, lds);
+    int rc = allow_big_lds(k_wgrad, lds);
     if (rc) return rc;
     once = true;
   }
-  const int tiles = (int)(cdiv(a.ka, 32 * MT) * cdiv(a.nb, 32 * NT));
+  long long rpw = cdiv(a.rows, (long long)4 * a.nsplit);
+  a.rows_per_wave = (rpw + 1) & ~1LL;
+  a.job[0].tiles_n = (a.job[0].nb + 63) / 64; a.job[0].ntiles = ((a.job[0].ka + 63) / 64) * a.job[0].tiles_n;
+  for (int k = 1; k < 3; ++k) { a.job[k].tiles_n = (a.job[k].nb + 63) / 64; a.job[k].ntiles = ((a.job[k].ka + 31) / 32) * a.job[k].tiles_n; }
+  a.tiles_total = a.job[0].ntiles + a.job[1].ntiles + a.job[2].ntiles;
+  const int sm = a.nsplit * a.members;
+  const int blocks = 8 * ((sm + 7) / 8) * a.tiles_total;
   ProfScope prof(PROF_WGRAD, st);
-  hipLaunchKernelGGL((k_wgrad<MT, NT>), dim3(tiles, nsplit, members), dim3(NTHREADS), lds, st, a);
+  hipLaunchKernelGGL(k_wgrad, dim3(blocks), dim3(NTHREADS), lds, st, a);
   MB_LAUNCH_OK("k_wgrad");
   return 0;
-}
-
-// Pick the wave tile from the operand widths; `a.rows_per_wave` is derived from nsplit here.
-int launch_wgrad(WgradArgs a, int members, int nsplit, hipStream_t st) {
-  if (a.rows <= 0) return 0;
-  long long rpw = cdiv(a.rows, (long long)4 * nsplit);
-  rpw = (rpw + 1) & ~1LL;
-  a.rows_per_wave = rpw;
-  if (a.ka <= 32) return launch_wgrad_t<1, 2>(a, members, nsplit, st);
-  if (a.nb <= 32) return launch_wgrad_t<2, 1>(a, members, nsplit, st);
-  return launch_wgrad_t<2, 2>(a, members, nsplit, st);
 }
 
 // ------------------------------------------------------------------------------------------------
 // slabs + bias partials -> gradient blob
 // ------------------------------------------------------------------------------------------------
+// Weight entries: one thread per entry sums the split-K slabs (coalesced across threads).  Bias entries: one
+// WAVE per entry strides over the row-tile partials and shuffle-reduces (a serial loop over ~160 dependent
+// L2 reads per thread made the first version of this kernel latency bound: 41 us instead of ~5).
 __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= a.L.total_floats) return;
-  const int m = (int)(j / a.L.member_floats);
-  const long long o = j - (long long)m * a.L.member_floats;
-  int bsel = -1, bidx = 0;     // bias segment: 0 -> db1, 1 -> db2, 2 -> db3
-  if (o >= a.L.b1 && o < a.L.b1 + HID) { bsel = 0; bidx = (int)(o - a.L.b1); }
-  else if (o >= a.L.b2 && o < a.L.b2 + HID) { bsel = 1; bidx = (int)(o - a.L.b2); }
-  else if (o >= a.L.b3) { bsel = 2; bidx = (int)(o - a.L.b3); }
-  float s = 0.f;
-  if (bsel < 0) {
+  const long long nW = a.L.total_floats;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < nW) {
+    const long long j = gid;
+    const long long o = j % a.L.member_floats;
+    const bool is_bias = (o >= a.L.b1 && o < a.L.b1 + HID) || (o >= a.L.b2 && o < a.L.b2 + HID) || (o >= a.L.b3);
+    if (is_bias) return;
+    float s = 0.f;
     for (int k = 0; k < a.nsplit; ++k) s += a.slabs[(long long)k * a.slab_stride + j];
-  } else {
-    const int per = 2 * HID + a.L.Np3;
-    const int off = bsel == 0 ? bidx : bsel == 1 ? HID + bidx : 2 * HID + bidx;
-    for (int t = 0; t < a.ntiles; ++t) s += a.dbp[((long long)t * a.L.members + m) * per + off];
+    a.grad[j] = s;
+    return;
   }
-  a.grad[j] = s;
+  // ---- bias part: wave index -> (member, bias element) ----
+  const int per = 2 * HID + a.L.Np3;
+  const long long wv = (gid - ((nW + 255) / 256) * 256) >> 6;
+  if (wv < 0 || wv >= (long long)a.L.members * per) return;
+  const int lane = threadIdx.x & 63;
+  const int m = (int)(wv / per), off = (int)(wv % per);
+  float s = 0.f;
+  for (int t = lane; t < a.ntiles; t += 64) s += a.dbp[((long long)t * a.L.members + m) * per + off];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) {
+    const long long dst = (long long)m * a.L.member_floats + (off < HID ? a.L.b1 + off : off < 2 * HID ? a.L.b2 + (off - HID) : a.L.b3 + (off - 2 * HID));
+    a.grad[dst] = s;
+  }
 }
 
 int launch_grad_reduce(const GradReduceArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)cdiv(a.L.total_floats, 256)), dim3(256), 0, st, a);
+  const long long wblocks = cdiv(a.L.total_floats, 256);
+  const long long bblocks = cdiv((long long)a.L.members * (2 * HID + a.L.Np3) * 64, 256);
+  hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, a);
   MB_LAUNCH_OK("k_grad_reduce");
   return 0;
 }

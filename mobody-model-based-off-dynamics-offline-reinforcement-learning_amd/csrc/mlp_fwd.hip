@@ -3,29 +3,32 @@
 // backward pass asks for them).  Roofline: MFMA f32 (2*(Kp1+256+Np3)*256 FLOP per row
 // against (in+out)*4 bytes per row -> AI > 1000 F/B); weights (<= 340 KB per member)
 // stream from L2.
+#include <stdlib.h>
+
 #include "common.h"
 #include "layers.h"
 
 namespace mobody {
 
-template <int ACT>
+template <int ACT, int MT>
 __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_fwd(Mlp3FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
+  constexpr int TB = 32 * MT;                     // rows of this workgroup's tile
   const int m = blockIdx.y;
-  const long long row0 = (long long)blockIdx.x * BM;
-  const int rows_here = (int)min((long long)BM, a.rows - row0);
+  const long long row0 = (long long)blockIdx.x * TB;
+  const int rows_here = (int)min((long long)TB, a.rows - row0);
 
   // ---- input tile: concat(src0, src1, src2), zero padded to Kp1 columns ----
   int c0 = 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     if (a.n[k] > 0) {
-      tile_load(Xs, c0, a.src[k] + row0 * a.ld[k], a.ld[k], a.n[k], 0, rows_here);
+      tile_load(Xs, c0, a.src[k] + row0 * a.ld[k], a.ld[k], a.n[k], 0, rows_here, TB);
       c0 += a.n[k];
     }
   }
-  tile_zero_cols(Xs, c0, a.Kp1);
-  __syncthreads();
+  tile_zero_cols(Xs, c0, a.Kp1, TB);
+  lds_barrier();
   if (a.save_x != nullptr && m == 0) {
     for (int idx = threadIdx.x; idx < rows_here * a.Kp1; idx += NTHREADS) {
       const int r = idx / a.Kp1, c = idx - r * a.Kp1;
@@ -40,8 +43,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_fwd(Mlp3FwdArgs a) {
       if (dst != nullptr && row < rows_here) dst[row * HID + col] = y;
     };
   };
-  wide_layer<ACT>(Xs, a.w1 + m * a.sw1, a.b1 + m * a.sb1, a.Kp1, saver(h1));
-  wide_layer<ACT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, saver(h2));
+  wide_layer<ACT, MT>(Xs, a.w1 + m * a.sw1, a.b1 + m * a.sb1, a.Kp1, saver(h1));
+  wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, saver(h2));
 
   const float* b3 = a.b3 + m * a.sb3;
   float* out = a.out + m * a.out_mstride + row0 * a.out_ld;
@@ -51,27 +54,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_fwd(Mlp3FwdArgs a) {
       if (a.out_mode == 1) y = a.max_action * tanhf(y);
       out[row * a.out_ld + col] = y;
     }
-  });
+  }, TB);
+}
+
+template <int ACT, int MT>
+static int launch_fwd_t(const Mlp3FwdArgs& a, int members, hipStream_t stream) {
+  size_t lds = (size_t)32 * MT * LDX * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    int rc = allow_big_lds(k_mlp3_fwd<ACT, MT>, 160 * 1024);
+    if (rc) return rc;
+    once = true;
+  }
+  if (const char* e = getenv("MOBODY_FWD_LDS_KB")) { size_t v = (size_t)atoi(e) * 1024; if (v > lds) lds = v; }
+  dim3 grid((unsigned)cdiv(a.rows, 32 * MT), (unsigned)members);
+  ProfScope prof(PROF_MLP_FWD, stream);
+  hipLaunchKernelGGL((k_mlp3_fwd<ACT, MT>), grid, dim3(NTHREADS), lds, stream, a);
+  MB_LAUNCH_OK("k_mlp3_fwd");
+  return 0;
 }
 
 int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stream) {
   if (a.rows <= 0) return 0;
-  static bool once = false;
-  if (!once) {
-    int rc = allow_big_lds(k_mlp3_fwd<ACT_RELU>, TILE_LDS_BYTES);
-    if (rc) return rc;
-    rc = allow_big_lds(k_mlp3_fwd<ACT_SWISH>, TILE_LDS_BYTES);
-    if (rc) return rc;
-    once = true;
-  }
-  dim3 grid((unsigned)cdiv(a.rows, BM), (unsigned)members);
-  ProfScope prof(PROF_MLP_FWD, stream);
-  if (act == ACT_SWISH)
-    hipLaunchKernelGGL(k_mlp3_fwd<ACT_SWISH>, grid, dim3(NTHREADS), TILE_LDS_BYTES, stream, a);
-  else
-    hipLaunchKernelGGL(k_mlp3_fwd<ACT_RELU>, grid, dim3(NTHREADS), TILE_LDS_BYTES, stream, a);
-  MB_LAUNCH_OK("k_mlp3_fwd");
-  return 0;
+  const bool small = pick_tile_rows(a.rows, members) == 32;
+  if (act == ACT_SWISH) return small ? launch_fwd_t<ACT_SWISH, 1>(a, members, stream) : launch_fwd_t<ACT_SWISH, 2>(a, members, stream);
+  return small ? launch_fwd_t<ACT_RELU, 1>(a, members, stream) : launch_fwd_t<ACT_RELU, 2>(a, members, stream);
 }
 
 }  // namespace mobody

@@ -38,6 +38,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits s_waitcnt vmcnt(0), which parks
+// every wave until its outstanding GLOBAL loads/stores (activation saves, prefetched masks) have retired;
+// nothing in these kernels hands global data between waves, so only lgkmcnt has to drain.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SWISH = 2 };
 
 template <int ACT>
@@ -51,52 +56,76 @@ __device__ __forceinline__ float activate(float x) {
 // wide GEMM:  acc[mt][nt] (+)= X[64 x Kp] (LDS) * W[Kp x 256] (global, row major, ld = 256)
 // Kp multiple of 8.  Columns of this wave: 64*w + 32*nt + (lane&31).
 // --------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wide_zero(f32x16 (&acc)[2][2]) {
+template <int MT>
+__device__ __forceinline__ void wide_zero(f32x16 (&acc)[MT][2]) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MT; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 }
 
+// MT = 2: 64-row workgroup tile (2x2 MFMA tiles per wave); MT = 1: 32-row tile (1x2), used when a launch has too
+// few 64-row tiles to fill 256 CUs (twice the workgroups, half the LDS, ~100 VGPRs -> 4 workgroups per CU).
+// Storage index of element (k, n) of a 256-column ("wide") weight matrix.  Wide matrices are stored K-interleaved
+// by four, [K/4][256][4]: the four k-steps one MFMA chunk needs for column n are 16 contiguous bytes, so a lane
+// fetches its B fragments for a whole chunk with ONE 16-byte load and a wave instruction reads 1 KB contiguous.
+__host__ __device__ inline long long wide_idx(int k, int n) { return ((long long)(k >> 2) * HID + n) * 4 + (k & 3); }
+
+template <int MT>
 __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const float* __restrict__ W, int Kp,
-                                          f32x16 (&acc)[2][2]) {
+                                          f32x16 (&acc)[MT][2]) {
+  constexpr int R = 5;                          // register ring: weight fragments are requested R-1 = 4 chunks ahead
   const int lane = lane_id(), w = wave_id();
   const int i = lane & 31, h = lane >> 5;
   const int kh = Kp >> 1;                       // K range of this lane half, multiple of 4
-  const float* xa0 = Xs + i * LDX + h * kh;
-  const float* xa1 = xa0 + 32 * LDX;
-  const float* wb = W + (size_t)(h * kh) * HID + 64 * w + i;
-  float b0[4], b1[4], nb0[4], nb1[4];
+  const int nch = kh >> 2;                      // chunks of four k-steps
+  const float* xa = Xs + i * LDX + h * kh;
+  const float* wb = W + ((size_t)(h * nch) * HID + 64 * w + i) * 4;
+  // One chunk is 8*MT MFMAs = 512*MT cycles of this wave's pipe time, while an L2 round trip under load is
+  // ~0.9 us (~2000 cycles): throughput per wave = bytes in flight / latency, so 4 chunks (2 KB per wave) are
+  // kept in flight.  (With 2 chunks of 4-byte loads the 640-workgroup twin-Q forward ran at 35 % MFMA busy.)
+  auto ldb = [&](int c, f32x4 (&b)[2]) {
+    const float* wn = wb + (size_t)c * (HID * 4);
+    b[0] = *reinterpret_cast<const f32x4*>(wn);
+    b[1] = *reinterpret_cast<const f32x4*>(wn + 128);
+  };
+  auto mma = [&](int c, f32x4 (&b)[2]) {
+    f32x4 av[MT];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) { b0[u] = wb[u * HID]; b1[u] = wb[u * HID + 32]; }
-  for (int t = 0; t < kh; t += 4) {
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(xa0 + t);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(xa1 + t);
-    const bool more = (t + 4) < kh;
-    const float* wn = wb + (size_t)(more ? t + 4 : t) * HID;   // prefetch next four k-rows (re-read last on the tail)
+    for (int x = 0; x < MT; ++x) av[x] = *reinterpret_cast<const f32x4*>(xa + 32 * x * LDX + 4 * c);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { nb0[u] = wn[u * HID]; nb1[u] = wn[u * HID + 32]; }
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+      for (int x = 0; x < MT; ++x) {
+        acc[x][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][u], b[0][u], acc[x][0], 0, 0, 0);
+        acc[x][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][u], b[1][u], acc[x][1], 0, 0, 0);
+      }
+  };
+  f32x4 ring[R][2];
+#pragma unroll
+  for (int j = 0; j < R - 1; ++j)
+    if (j < nch) ldb(j, ring[j]);
+  for (int c0 = 0; c0 < nch; c0 += R) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int c = c0 + j;
+      if (c < nch) {
+        if (c + R - 1 < nch) ldb(c + R - 1, ring[(j + R - 1) % R]);
+        mma(c, ring[j]);
+      }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { b0[u] = nb0[u]; b1[u] = nb1[u]; }
   }
 }
 
-// Visit every accumulator element of a wide result: f(row 0..63, col 0..255, value).
-template <class F>
-__device__ __forceinline__ void wide_foreach(f32x16 (&acc)[2][2], F&& f) {
+// Visit every accumulator element of a wide result: f(row 0..32*MT-1, col 0..255, value).
+template <int MT, class F>
+__device__ __forceinline__ void wide_foreach(f32x16 (&acc)[MT][2], F&& f) {
   const int lane = lane_id(), w = wave_id();
   const int i = lane & 31, h = lane >> 5;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -114,10 +143,19 @@ __device__ __forceinline__ void wide_foreach(f32x16 (&acc)[2][2], F&& f) {
 // --------------------------------------------------------------------------------------------
 template <int NT>
 __device__ __forceinline__ void narrow_gemm(const float* __restrict__ Xs, const float* __restrict__ W, int Kp, int Np,
-                                            int nt0, f32x4 (&acc)[NT]) {
+                                            int nt0, f32x4 (&acc)[NT], int bm = BM) {
+  constexpr int C = 8 / NT;                      // k-pairs per prefetch chunk (8 MFMAs per chunk and accumulator pair)
   const int lane = lane_id(), w = wave_id();
+  if (16 * w >= bm) {                            // 32-row tiles: waves 2,3 own no rows in a narrow layer (wave uniform)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[n][r] = 0.f;
+    return;
+  }
   const int i = lane & 15, q = lane >> 4;
   const int kq = Kp >> 2;                       // K range of this lane quarter, multiple of 2
+  const int steps = kq >> 1;                    // k-pairs
   const float* xa = Xs + (16 * w + i) * LDX + q * kq;
   const float* wb = W + (size_t)(q * kq) * Np + 16 * nt0 + i;
   f32x4 acc2[NT];                               // second chain hides the 40-cycle dependent latency
@@ -125,14 +163,37 @@ __device__ __forceinline__ void narrow_gemm(const float* __restrict__ Xs, const 
   for (int n = 0; n < NT; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { acc[n][r] = 0.f; acc2[n][r] = 0.f; }
-  for (int t = 0; t < kq; t += 2) {
-    const float2 a = *reinterpret_cast<const float2*>(xa + t);
+  // Weight fragments of a whole chunk are requested before the chunk's MFMAs and one chunk ahead (two register
+  // sets): loading each fragment right before its MFMA exposed one L2 round trip per k-pair (64 per K=256 layer).
+  auto loadB = [&](int p, float (&bv)[C][2][NT]) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const float bx = wb[(size_t)t * Np + 16 * n];
-      const float by = wb[(size_t)(t + 1) * Np + 16 * n];
-      acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bx, acc[n], 0, 0, 0);
-      acc2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, by, acc2[n], 0, 0, 0);
+    for (int c = 0; c < C; ++c) {
+      const int t = 2 * min(p + c, steps - 1);   // clamped: tail steps re-read the last pair (their A is zeroed)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { bv[c][0][n] = wb[(size_t)t * Np + 16 * n]; bv[c][1][n] = wb[(size_t)(t + 1) * Np + 16 * n]; }
+    }
+  };
+  auto mma = [&](int p, float (&bv)[C][2][NT]) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const bool ok = (p + c) < steps;
+      float2 av = *reinterpret_cast<const float2*>(xa + 2 * min(p + c, steps - 1));
+      av.x = ok ? av.x : 0.f; av.y = ok ? av.y : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[c][0][n], acc[n], 0, 0, 0);
+        acc2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[c][1][n], acc2[n], 0, 0, 0);
+      }
+    }
+  };
+  float b0[C][2][NT], b1[C][2][NT];
+  loadB(0, b0);
+  for (int p = 0; p < steps; p += 2 * C) {
+    if (p + C < steps) loadB(p + C, b1);
+    mma(p, b0);
+    if (p + C < steps) {
+      if (p + 2 * C < steps) loadB(p + 2 * C, b0);
+      mma(p + C, b1);
     }
   }
 #pragma unroll
@@ -144,14 +205,15 @@ __device__ __forceinline__ void narrow_gemm(const float* __restrict__ Xs, const 
 // Run a narrow layer over all Np/16 column tiles in groups of <= 2; f(row 0..63, col, value).
 template <class F>
 __device__ __forceinline__ void narrow_layer(const float* __restrict__ Xs, const float* __restrict__ W, int Kp, int Np,
-                                             F&& f) {
+                                             F&& f, int bm = BM) {
   const int lane = lane_id(), w = wave_id();
   const int i = lane & 15, q = lane >> 4;
   const int ntiles = Np >> 4;
+  if (16 * w >= bm) return;
   int nt0 = 0;
   for (; nt0 + 2 <= ntiles; nt0 += 2) {
     f32x4 acc[2];
-    narrow_gemm<2>(Xs, W, Kp, Np, nt0, acc);
+    narrow_gemm<2>(Xs, W, Kp, Np, nt0, acc, bm);
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -159,7 +221,7 @@ __device__ __forceinline__ void narrow_layer(const float* __restrict__ Xs, const
   }
   if (nt0 < ntiles) {
     f32x4 acc[1];
-    narrow_gemm<1>(Xs, W, Kp, Np, nt0, acc);
+    narrow_gemm<1>(Xs, W, Kp, Np, nt0, acc, bm);
 #pragma unroll
     for (int r = 0; r < 4; ++r) f(16 * w + 4 * q + r, 16 * nt0 + i, acc[0][r]);
   }
@@ -169,17 +231,31 @@ __device__ __forceinline__ void narrow_layer(const float* __restrict__ Xs, const
 // LDS tile fill: X[r][col0 + c] = src[(row0+r)*ld + c] for c < n (zero for rows >= rows).
 // --------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tile_load(float* Xs, int col0, const float* __restrict__ src, int ld, int n, int row0,
-                                          int rows) {
-  for (int idx = threadIdx.x; idx < BM * n; idx += NTHREADS) {
-    const int r = idx / n, c = idx - r * n;
-    const int gr = row0 + r;
-    Xs[r * LDX + col0 + c] = (gr < rows) ? src[(size_t)gr * ld + c] : 0.f;
+                                          int rows, int bm = BM) {
+  // Four elements per thread and pass: all loads of a pass are issued before the first LDS write (a load followed
+  // directly by its dependent ds_write costs one HBM round trip per element).  Loads are unconditional from a
+  // clamped row (a conditional load would branch and drain vmcnt per element); invalid rows are zeroed by select.
+  const int total = bm * n;
+  for (int base = 0; base < total; base += 4 * NTHREADS) {
+    float v[4]; int dst[4]; bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = min(base + u * NTHREADS + (int)threadIdx.x, total - 1);
+      const int r = idx / n, c = idx - r * n;
+      const int gr = row0 + r;
+      v[u] = src[(size_t)min(gr, rows - 1) * ld + c];
+      ok[u] = gr < rows;
+      dst[u] = r * LDX + col0 + c;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (base + u * NTHREADS + (int)threadIdx.x < total) Xs[dst[u]] = ok[u] ? v[u] : 0.f;
   }
 }
-__device__ __forceinline__ void tile_zero_cols(float* Xs, int c0, int c1) {
+__device__ __forceinline__ void tile_zero_cols(float* Xs, int c0, int c1, int bm = BM) {
   const int n = c1 - c0;
   if (n <= 0) return;
-  for (int idx = threadIdx.x; idx < BM * n; idx += NTHREADS) {
+  for (int idx = threadIdx.x; idx < bm * n; idx += NTHREADS) {
     const int r = idx / n, c = idx - r * n;
     Xs[r * LDX + c0 + c] = 0.f;
   }

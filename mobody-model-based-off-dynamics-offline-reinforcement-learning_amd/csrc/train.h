@@ -18,16 +18,23 @@ struct Mlp3BwdArgs {
   float* dx;               // [members][rows][dx_n] input gradient columns [dx_c0, dx_c0 + dx_n)  (DX only)
   int dx_c0, dx_n;
 };
-int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, hipStream_t st);
+int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, int tile_rows, hipStream_t st);
 
-struct WgradArgs {
-  const float* A; long long a_mstride; int lda, ka;    // A[rows][lda], columns < ka contribute
-  const float* B; long long b_mstride; int ldb, nb;    // B[rows][ldb], columns < nb contribute
-  long long rows, rows_per_wave;
-  float* slabs; long long slab_stride;                 // partial slab s = slabs + s*slab_stride (gradient-blob layout)
-  long long out_off, out_mstride; int out_ld, out_k, out_n;
+struct WgradJob {
+  const float* A; long long a_mstride; int lda, ka;    // A[rows][lda], columns < ka contribute (output rows)
+  const float* B; long long b_mstride; int ldb, nb;    // B[rows][ldb], columns < nb contribute (output cols)
+  long long out_off; int out_ld, out_k, out_n;         // slab + out_off + m*out_mstride + k*out_ld + n  (k<out_k, n<out_n)
+  int transposed;                                      // store [n][k] instead (used for dW3, computed as dz3^T h2)
+  int wide;                                            // destination is a 256-wide matrix in wide_idx storage
+  int tiles_n, ntiles;                                 // filled by launch_wgrad
 };
-int launch_wgrad(WgradArgs a, int members, int nsplit, hipStream_t st);
+struct WgradArgs {
+  WgradJob job[3];                                     // job 0: 64x64 wave tiles, jobs 1-2: 32x64
+  long long rows, rows_per_wave;
+  float* slabs; long long slab_stride, out_mstride;    // partial slab s = slabs + s*slab_stride (gradient-blob layout)
+  int nsplit, members, tiles_total;
+};
+int launch_wgrad(WgradArgs a, hipStream_t st);
 
 struct GradReduceArgs {
   MobodyMlpLayout L;

@@ -17,9 +17,9 @@ namespace mobody {
 // workspace carving
 // ------------------------------------------------------------------------------------------------
 struct TrainWs {
-  float *pi, *qt, *q, *qb, *xq, *h1q, *h2q, *xa, *h1a, *h2a, *dz3q, *dz2, *dz1, *dz3a, *dxa, *bcw, *dbp, *slabs;
+  float *pi, *qt, *q, *qb, *xq, *h1q, *h2q, *xa, *h1a, *h2a, *dz3q, *dz2, *dz1, *dz3a, *dxa, *bcw, *dbp, *slabs, *lossp;
   long long slab_stride, total;
-  int nsplit, ntiles;
+  int nsplit, ntiles, tile_rows;
   MobodyMlpLayout Lq, La;
 };
 
@@ -47,7 +47,9 @@ static int carve(const MobodyTrainDims& d, float* base, TrainWs& w) {
   w.dz3a = take(N * w.La.Np3);
   w.dxa = take(2 * N * d.A);
   w.bcw = take(Nt > 0 ? Nt : 1);
-  w.ntiles = (int)cdiv(N, BM);
+  w.lossp = take(2 * cdiv(N, 256));
+  w.tile_rows = pick_tile_rows(N, 1);             // one value for both nets: the bias partials are per row tile
+  w.ntiles = (int)cdiv(N, w.tile_rows);
   w.nsplit = wgrad_nsplit(N);
   const long long per_q = 2 * HID + w.Lq.Np3, per_a = 2 * HID + w.La.Np3;
   w.dbp = take((long long)w.ntiles * (2 * per_q > per_a ? 2 * per_q : per_a));
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(1024) void k_actor_stats(const float* qp, const flo
 
 struct ActorRowArgs {
   const float *qp, *qb, *stats, *pi, *act, *dxa;
-  float *dz3q, *bcw, *dz3a, *loss_out;
+  float *dz3q, *bcw, *dz3a, *loss_out, *lossp;
   long long N, Nt, Ng, Ntg;
   int A, Np3q, Np3a;
   MobodyHyper h;
@@ -152,36 +154,41 @@ __global__ __launch_bounds__(256) void k_actor_prep(ActorRowArgs a) {
   if (row < a.Nt) a.bcw[row] = bc_weight(a, row);
 }
 
-// dL/d(pre-tanh) of the actor: Q path (sum of both members' dx) + BC path on the first Nt rows.
+// dL/d(pre-tanh) of the actor: Q path (sum of both members' dx) + BC path on the first Nt rows.  Also emits the
+// per-workgroup partial sums of the two loss terms (sum -min q, sum w*(pi-a)^2) for k_actor_loss.
 __global__ __launch_bounds__(256) void k_actor_dpi(ActorRowArgs a) {
+  __shared__ float sm[4];
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= a.N) return;
-  const float wbc = row < a.Nt ? a.h.bc_coef * 2.f * a.bcw[row] / ((float)a.Ntg * (float)a.A) : 0.f;
-  float* o = a.dz3a + row * a.Np3a;
-  for (int j = 0; j < a.Np3a; ++j) {
-    float v = 0.f;
-    if (j < a.A) {
-      const float p = a.pi[row * a.A + j];
-      float d = a.dxa[row * a.A + j] + a.dxa[(a.N + row) * a.A + j];
-      if (row < a.Nt) d += wbc * (p - a.act[row * a.A + j]);
-      const float t = p / a.h.max_action;
-      v = d * a.h.max_action * (1.f - t * t);                   // d tanh
+  float s0 = 0.f, s1 = 0.f;
+  if (row < a.N) {
+    const float w = row < a.Nt ? a.bcw[row] : 0.f;
+    const float wbc = a.h.bc_coef * 2.f * w / ((float)a.Ntg * (float)a.A);
+    float* o = a.dz3a + row * a.Np3a;
+    float e = 0.f;
+    for (int j = 0; j < a.Np3a; ++j) {
+      float v = 0.f;
+      if (j < a.A) {
+        const float p = a.pi[row * a.A + j];
+        float d = a.dxa[row * a.A + j] + a.dxa[(a.N + row) * a.A + j];
+        if (row < a.Nt) { const float df = p - a.act[row * a.A + j]; d += wbc * df; e += df * df; }
+        const float t = p / a.h.max_action;
+        v = d * a.h.max_action * (1.f - t * t);                   // d tanh
+      }
+      o[j] = v;
     }
-    o[j] = v;
+    s0 = -fminf(a.qp[row], a.qp[a.N + row]);
+    s1 = w * e;
   }
+  s0 = block_sum(s0, sm);
+  s1 = block_sum(s1, sm);
+  if (threadIdx.x == 0) { a.lossp[2 * blockIdx.x] = s0; a.lossp[2 * blockIdx.x + 1] = s1; }
 }
 
 // loss_out[0] = p_w*mean(-q) + bc_coef*L_BC, loss_out[1] = L_BC   (local shares of the global means)
-__global__ __launch_bounds__(1024) void k_actor_loss(ActorRowArgs a) {
-  __shared__ float sm[16];
+__global__ __launch_bounds__(256) void k_actor_loss(ActorRowArgs a, int nparts) {
+  __shared__ float sm[4];
   float s0 = 0.f, s1 = 0.f;
-  for (long long row = threadIdx.x; row < a.N; row += blockDim.x) s0 -= fminf(a.qp[row], a.qp[a.N + row]);
-  for (long long row = threadIdx.x; row < a.Nt; row += blockDim.x) {
-    const float w = a.bcw[row];
-    float e = 0.f;
-    for (int j = 0; j < a.A; ++j) { const float d = a.pi[row * a.A + j] - a.act[row * a.A + j]; e += d * d; }
-    s1 += w * e;
-  }
+  for (int k = threadIdx.x; k < nparts; k += blockDim.x) { s0 += a.lossp[2 * k]; s1 += a.lossp[2 * k + 1]; }
   s0 = block_sum(s0, sm);
   s1 = block_sum(s1, sm);
   if (threadIdx.x == 0) {
@@ -213,6 +220,8 @@ __global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m
   if (target != nullptr) target[j] = c.tau * pj + c.one_minus_tau * target[j];      // update_target :183-187
 }
 
+// W1 and W2 (and W3T, W2T of the T blob) are 256 columns wide and stored K-interleaved (tile.h wide_idx);
+// W3 and W1T are narrow and row major.
 __global__ __launch_bounds__(256) void k_mlp_transpose(MobodyMlpLayout L, const float* blob, float* bt) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= L.t_total_floats) return;
@@ -220,17 +229,17 @@ __global__ __launch_bounds__(256) void k_mlp_transpose(MobodyMlpLayout L, const 
   const long long o = j - (long long)m * L.t_member_floats;
   const float* src = blob + (long long)m * L.member_floats;
   float val;
-  if (o < L.w2t) {                               // W3T[n][k] = W3[k][n]
-    const int n = (int)(o / HID), k = (int)(o % HID);
-    val = src[L.w3 + (long long)k * L.Np3 + n];
-  } else if (o < L.w1t) {                        // W2T[n][k] = W2[k][n]
-    const long long oo = o - L.w2t;
-    const int n = (int)(oo / HID), k = (int)(oo % HID);
-    val = src[L.w2 + (long long)k * HID + n];
-  } else {                                       // W1T[n][k] = W1[k][n], zero for k >= Kp1
+  if (o < L.w1t) {                               // wide regions of the T blob: decode (row kk, column c) of storage slot o
+    const bool is3 = o < L.w2t;
+    const long long oo = is3 ? o : o - L.w2t;
+    const long long g = oo >> 2;
+    const int kk = (int)(g / HID) * 4 + (int)(oo & 3), c = (int)(g % HID);
+    // W3T[n3 = kk][k = c] = W3[k][n3] (narrow, row major);  W2T[n = kk][k = c] = W2[k][n] (wide)
+    val = is3 ? src[L.w3 + (long long)c * L.Np3 + kk] : src[L.w2 + wide_idx(c, kk)];
+  } else {                                       // W1T[n][k] = W1[k][n] (narrow [256][Np1t]), zero for k >= Kp1
     const long long oo = o - L.w1t;
     const int n = (int)(oo / L.Np1t), k = (int)(oo % L.Np1t);
-    val = k < L.Kp1 ? src[L.w1 + (long long)k * HID + n] : 0.f;
+    val = k < L.Kp1 ? src[L.w1 + wide_idx(k, n)] : 0.f;
   }
   bt[j] = val;
 }
@@ -253,29 +262,21 @@ static Mlp3FwdArgs fwd_args(const float* blob, const MobodyMlpLayout& L, const f
   return a;
 }
 
-// weight gradients of one packed MLP: three split-K GEMMs + the deterministic reduction
+// weight gradients of one packed MLP: one merged split-K launch + the deterministic reduction
 static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h1, const float* h2, const float* dz3,
                         const float* dz2, const float* dz1, long long rows, const TrainWs& w, float* grad,
                         hipStream_t st) {
-  const int M = L.members;
   WgradArgs g{};
   g.rows = rows; g.slabs = w.slabs; g.slab_stride = w.slab_stride; g.out_mstride = L.member_floats;
-  // dW1 = x^T dz1   (x is shared by the members)
-  g.A = x; g.a_mstride = 0; g.lda = L.Kp1; g.ka = L.Kp1;
-  g.B = dz1; g.b_mstride = rows * HID; g.ldb = HID; g.nb = HID;
-  g.out_off = L.w1; g.out_ld = HID; g.out_k = L.Kp1; g.out_n = HID;
-  int rc = launch_wgrad(g, M, w.nsplit, st);
-  if (rc) return rc;
+  g.nsplit = w.nsplit; g.members = L.members;
+  const long long hs = rows * HID;
   // dW2 = h1^T dz2
-  g.A = h1; g.a_mstride = rows * HID; g.lda = HID; g.ka = HID;
-  g.B = dz2; g.out_off = L.w2; g.out_k = HID;
-  rc = launch_wgrad(g, M, w.nsplit, st);
-  if (rc) return rc;
-  // dW3 = h2^T dz3
-  g.A = h2;
-  g.B = dz3; g.b_mstride = rows * L.Np3; g.ldb = L.Np3; g.nb = L.Np3;
-  g.out_off = L.w3; g.out_ld = L.Np3; g.out_n = L.Np3;
-  rc = launch_wgrad(g, M, w.nsplit, st);
+  g.job[0] = WgradJob{h1, hs, HID, HID, dz2, hs, HID, HID, L.w2, HID, HID, HID, 0, 1, 0, 0};
+  // dW1 = x^T dz1   (x is shared by the members)
+  g.job[1] = WgradJob{x, 0, L.Kp1, L.Kp1, dz1, hs, HID, HID, L.w1, HID, L.Kp1, HID, 0, 1, 0, 0};
+  // dW3^T = dz3^T h2, stored transposed into W3[256][Np3]
+  g.job[2] = WgradJob{dz3, rows * L.Np3, L.Np3, L.Np3, h2, hs, HID, HID, L.w3, L.Np3, L.Np3, HID, 1, 0, 0, 0};
+  int rc = launch_wgrad(g, st);
   if (rc) return rc;
   GradReduceArgs r{L, w.slabs, w.slab_stride, w.nsplit, w.dbp, w.ntiles, grad};
   return launch_grad_reduce(r, st);
@@ -330,7 +331,7 @@ extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h
   MB_LAUNCH_OK("k_td_prep");
   hipLaunchKernelGGL(k_td_loss, dim3(1), dim3(1024), 0, st, w.qt, w.q, reward, not_done, N, h->gamma, invNg, loss_out);
   MB_LAUNCH_OK("k_td_loss");
-  rc = launch_mlp3_bwd(bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp), 2, false, st);
+  rc = launch_mlp3_bwd(bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp), 2, false, w.tile_rows, st);
   if (rc) return rc;
   return weight_grads(w.Lq, w.xq, w.h1q, w.h2q, w.dz3q, w.dz2, w.dz1, N, w, grad_q, st);
 }
@@ -376,7 +377,7 @@ extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper
   const long long N = d->N;
   ActorRowArgs ra{};
   ra.qp = w.q; ra.qb = w.qb; ra.stats = stats; ra.pi = w.pi; ra.act = action; ra.dxa = w.dxa;
-  ra.dz3q = w.dz3q; ra.bcw = w.bcw; ra.dz3a = w.dz3a; ra.loss_out = loss_out;
+  ra.dz3q = w.dz3q; ra.bcw = w.bcw; ra.dz3a = w.dz3a; ra.loss_out = loss_out; ra.lossp = w.lossp;
   ra.N = N; ra.Nt = d->Nt; ra.Ng = d->N_global; ra.Ntg = d->Nt_global > 0 ? d->Nt_global : 1;
   ra.A = d->A; ra.Np3q = w.Lq.Np3; ra.Np3a = w.La.Np3; ra.h = *h;
   const unsigned gb = (unsigned)cdiv(N, 256);
@@ -385,13 +386,13 @@ extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper
   // dq -> d(action) through the frozen twin-Q (parameters get no gradient, mobody.py:555-556)
   Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, nullptr, nullptr, w.dbp);
   bq.dx = w.dxa; bq.dx_c0 = d->S; bq.dx_n = d->A;
-  rc = launch_mlp3_bwd(bq, 2, true, st);
+  rc = launch_mlp3_bwd(bq, 2, true, w.tile_rows, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_actor_dpi, dim3(gb), dim3(256), 0, st, ra);
   MB_LAUNCH_OK("k_actor_dpi");
-  hipLaunchKernelGGL(k_actor_loss, dim3(1), dim3(1024), 0, st, ra);
+  hipLaunchKernelGGL(k_actor_loss, dim3(1), dim3(256), 0, st, ra, (int)gb);
   MB_LAUNCH_OK("k_actor_loss");
-  rc = launch_mlp3_bwd(bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp), 1, false, st);
+  rc = launch_mlp3_bwd(bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp), 1, false, w.tile_rows, st);
   if (rc) return rc;
   return weight_grads(w.La, w.xa, w.h1a, w.h2a, w.dz3a, w.dz2, w.dz1, N, w, grad_actor, st);
 }

@@ -16,6 +16,18 @@ from . import _lib
 MLP_KEYS = ("network.0", "network.2", "network.4")
 
 
+def wide_pack(W):
+    """[..., K, 256] row-major -> the kernels' K-interleaved-by-4 storage [..., K/4, 256, 4] (csrc/tile.h wide_idx)."""
+    *lead, K, N = W.shape
+    assert N == 256 and K % 4 == 0
+    return W.reshape(*lead, K // 4, 4, N).transpose(-1, -2).contiguous()
+
+
+def wide_unpack(flat, K):
+    """Inverse of wide_pack for one matrix: flat [K*256] -> [K, 256]."""
+    return flat.reshape(K // 4, 256, 4).transpose(-1, -2).reshape(K, 256)
+
+
 def pack_dynamics(params, S, A, device):
     """params: dict name -> array/tensor in the reference layout. Returns a flat fp32 device blob."""
     L = _lib.dyn_layout(S, A)
@@ -31,6 +43,8 @@ def pack_dynamics(params, S, A, device):
         Wp[:, :K, :n] = W[:, :, :n]
         bp = torch.zeros(E, lay.Np, dtype=torch.float32, device=device)
         bp[:, :n] = b[:, 0, :n]
+        if lay.Np == 256:                                   # 256-wide matrices use the interleaved storage
+            Wp = wide_pack(Wp)
         blob[lay.w_off:lay.w_off + Wp.numel()] = Wp.reshape(-1)
         blob[lay.b_off:lay.b_off + bp.numel()] = bp.reshape(-1)
     return blob
@@ -53,7 +67,7 @@ def pack_mlp(member_params, in_dim, out_dim, device, prefixes=None):
         w1 = torch.zeros(L.Kp1, 256, device=device); w1[:in_dim] = W1.t()
         w3 = torch.zeros(256, L.Np3, device=device); w3[:, :out_dim] = W3.t()
         b3 = torch.zeros(L.Np3, device=device); b3[:out_dim] = g("network.4.bias")
-        for off, t in ((L.w1, w1), (L.b1, g("network.0.bias")), (L.w2, W2.t().contiguous()),
+        for off, t in ((L.w1, wide_pack(w1)), (L.b1, g("network.0.bias")), (L.w2, wide_pack(W2.t().contiguous())),
                        (L.b2, g("network.2.bias")), (L.w3, w3), (L.b3, b3)):
             blob[base + off:base + off + t.numel()] = t.reshape(-1)
     return blob
@@ -67,9 +81,9 @@ def unpack_mlp(blob, in_dim, out_dim, members):
         base = m * L.member_floats
         v = lambda off, n: blob[base + off:base + off + n]
         out.append({
-            "network.0.weight": v(L.w1, L.Kp1 * 256).view(L.Kp1, 256)[:in_dim].t().contiguous(),
+            "network.0.weight": wide_unpack(v(L.w1, L.Kp1 * 256), L.Kp1)[:in_dim].t().contiguous(),
             "network.0.bias": v(L.b1, 256).clone(),
-            "network.2.weight": v(L.w2, 65536).view(256, 256).t().contiguous(),
+            "network.2.weight": wide_unpack(v(L.w2, 65536), 256).t().contiguous(),
             "network.2.bias": v(L.b2, 256).clone(),
             "network.4.weight": v(L.w3, 256 * L.Np3).view(256, L.Np3)[:, :out_dim].t().contiguous(),
             "network.4.bias": v(L.b3, L.Np3)[:out_dim].clone(),

@@ -199,10 +199,11 @@ def test_adam_polyak_kernel(dev):
         close(p, P, rtol=2e-6, atol=1e-7); close(tg, TG, rtol=2e-6, atol=1e-7)
         # the kernel uses torch's lerp form m + (1-b1)(g-m); the oracle uses b1*m + (1-b1)*g: 1-ulp-of-g apart
         close(m, M, rtol=2e-6, atol=1e-8); close(v, V, rtol=2e-6, atol=1e-20)
-    # the transposed blob mirrors the updated parameters
-    W2 = p[L.w2:L.w2 + 65536].view(256, 256)
-    close(pt[L.w2t:L.w2t + 65536].view(256, 256), W2.t(), rtol=0, atol=0)
+    # the transposed blob mirrors the updated parameters (256-wide matrices use the interleaved storage)
+    from mobody_amd import packing
+    W2 = packing.wide_unpack(p[L.w2:L.w2 + 65536], 256)
+    close(packing.wide_unpack(pt[L.w2t:L.w2t + 65536], 256), W2.t(), rtol=0, atol=0)
     W3 = p[L.w3:L.w3 + 256 * L.Np3].view(256, L.Np3)
-    close(pt[L.w3t:L.w3t + 256 * L.Np3].view(L.Np3, 256), W3.t(), rtol=0, atol=0)
-    W1 = p[L.w1:L.w1 + L.Kp1 * 256].view(L.Kp1, 256)
+    close(packing.wide_unpack(pt[L.w3t:L.w3t + 256 * L.Np3], L.Np3), W3.t(), rtol=0, atol=0)
+    W1 = packing.wide_unpack(p[L.w1:L.w1 + L.Kp1 * 256], L.Kp1)
     close(pt[L.w1t:L.w1t + 256 * L.Np1t].view(256, L.Np1t)[:, :L.Kp1], W1.t(), rtol=0, atol=0)
