@@ -52,7 +52,7 @@ def train_flops(N, Nt):
     return {"k_mlp3_fwd": 2.0 * fwd, "k_mlp3_bwd": 2.0 * bwd, "k_wgrad": 2.0 * wg}
 
 
-def build(dev, rank, bs):
+def build(dev, rank, bs, graph):
     from mobody_amd import synthetic
     from mobody_amd.algo import utils
     from mobody_amd.algo.call_algo import call_algo
@@ -60,7 +60,7 @@ def build(dev, rank, bs):
     from mobody_amd.algo.dynamics.mobody_module import MOBODYModule
     from mobody_amd.algo.mb_utils.terminal_funs import get_termination_fn
     import golden_util as gu
-    cfg = gu.policy_cfg(S, A, rng="device", seed=rank, penalty_type="none", batch_size=bs)
+    cfg = gu.policy_cfg(S, A, rng="device", seed=rank, penalty_type="none", batch_size=bs, graph=graph)
     torch.manual_seed(rank); np.random.seed(rank)
     pol = call_algo("mobody", cfg, 3, dev)
     src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=1000000, rng="device", seed=100 + rank), 1000000, TASK, rank)
@@ -71,9 +71,11 @@ def build(dev, rank, bs):
 
 
 def prof_pass(pol, src, tar, bs, steps):
-    """Instrumented pass: HIP event pairs around every launch of the heavy kernel families (library hook)."""
+    """Instrumented pass: HIP event pairs around every launch of the heavy kernel families (library hook).
+    Runs eagerly (event records are not part of a captured graph); the kernels are the same."""
     from mobody_amd import _lib
     lib = _lib.load()
+    pol.use_graph = False
     _lib.check(lib.mobody_prof_begin(steps * 64), "prof_begin")
     for _ in range(steps):
         pol.train(src, tar, bs, None, None)
@@ -143,18 +145,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch_size", type=int, default=BS)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="replay the steady-state step as a captured HIP graph (1 GPU only)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") over xGMI in production; MOBODY_BENCH_BACKEND=gloo only to rehearse the multi-process
+        # path with several ranks sharing one GPU (RCCL refuses duplicate devices)
+        backend = os.environ.get("MOBODY_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
     bs = args.batch_size
     N, Nt = int(2.5 * bs), 2 * bs
-    pol, src, tar, cfg = build(dev, rank, bs)
+    pol, src, tar, cfg = build(dev, rank, bs, args.graph)
 
     def barrier():
         if world > 1:
@@ -175,15 +184,16 @@ def main():
     dt = float(t.item())
     losses = pol.losses()
 
+    # the instrumented passes call train() (collectives when world > 1): every rank runs them, rank 0 reports
+    fam = prof_pass(pol, src, tar, bs, 20)
+    roll_rate, roll_ms, dynfwd_ms = rollout_rate(pol, src)
     out = None
     if rank == 0:
-        fam = prof_pass(pol, src, tar, bs, 20)
         fl = train_flops(N, Nt)
         kern = {}
         for k in ("k_mlp3_fwd", "k_mlp3_bwd", "k_wgrad"):
             ms, cnt = fam[k]
             kern[k] = dict(launches_per_step=cnt, ms_per_step=ms, tflops=fl[k] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
-        roll_rate, roll_ms, dynfwd_ms = rollout_rate(pol, src)
         _, _, dyn = macs()
         kern["k_dyn_fwd"] = dict(launches_per_step=1, ms_per_step=dynfwd_ms,
                                  tflops=2.0 * (dyn - 7 * ((2 * S + A) * 256 + 65536 + 512)) * 50000 / (dynfwd_ms * 1e-3) / 1e12)
@@ -201,7 +211,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"walker2d-friction shapes S={S} A={A}, ensemble 7, rollout_len 1, batch_size {bs}/GPU "
                                    f"(N={N} rows per train() step: src|tar|fake = {bs}|{bs}|{bs // 2}), fp32 MFMA",
-                       "rows_per_step_per_gpu": N, "parallelism": f"dp{world}"},
+                       "rows_per_step_per_gpu": N, "parallelism": f"dp{world}",
+                       "hip_graph": bool(args.graph and world == 1)},
             "grad_steps_per_sec": args.steps / dt,
             "rollout_transitions_per_sec": roll_rate, "rollout_ms_per_50000": roll_ms,
             "rollout_refresh_amortised_ms_per_step": (152000.0 / roll_rate) * 1e3 / 5000.0,

@@ -211,6 +211,12 @@ int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const 
 int mobody_adam_polyak(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad, float* m,
                        float* v, float* target, int64_t t, float lr, float tau, float grad_scale, void* stream);
 
+/* Same, with the 1-based step count read from DEVICE memory (t_dev[0]) so that a captured HIP graph advances
+ * without new kernel arguments (bias corrections are formed in double on the device). */
+int mobody_adam_polyak_dev(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad,
+                           float* m, float* v, float* target, const int64_t* t_dev, float lr, float tau,
+                           float grad_scale, void* stream);
+
 /* PAR reward shaping: reward[i] -= coef * mean_d (next_state_true[i][d] - next_state_model[i][d])^2  (mobody.py:428-434) */
 int mobody_par_penalty(const float* next_state_true, const float* next_state_model, float* reward, float coef,
                        int64_t n, int S, void* stream);

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "mobody_actor_backward": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp,
                                         vp, vp, vp, vp, vp]),
     "mobody_adam_polyak": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp]),
+    "mobody_adam_polyak_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "mobody_par_penalty": (C.c_int, [vp, vp, vp, f32, i64, C.c_int, vp]),
     "mobody_mlp_transpose": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp]),
 }

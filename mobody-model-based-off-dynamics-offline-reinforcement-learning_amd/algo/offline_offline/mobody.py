@@ -89,6 +89,12 @@ class _Adam(object):
         ops.adam_polyak(n.in_dim, n.out_dim, n.members, n.blob, n.blob_T, self.grad, self.m, self.v,
                         None if target is None else target.blob, self.t, self.lr, tau, grad_scale)
 
+    def step_dev(self, t_dev, target=None, tau=-1.0):
+        """Graph-capturable step: the 1-based step count is read from the device word `t_dev` (already advanced)."""
+        n = self.net
+        ops.adam_polyak_dev(n.in_dim, n.out_dim, n.members, n.blob, n.blob_T, self.grad, self.m, self.v,
+                            None if target is None else target.blob, t_dev, self.lr, tau, 1.0)
+
     def _unpack(self, blob):
         n = self.net
         out = []
@@ -149,6 +155,11 @@ class MOBODY(object):
         self._stats = torch.zeros(2, dtype=torch.float32, device=self.device)
         self._batch, self._batch_key = None, None
         self.last_losses = None
+        # HIP-graph replay of the steady-state step (config['graph']=1, rng='device', single GPU, no PAR/DARA):
+        # all per-step scalars (RNG call id, Adam step counts, buffer sizes) live in device words.
+        self.use_graph = bool(config.get("graph", 0))
+        self._graph, self._graph_key = None, None
+        self._ctr = torch.zeros(3, dtype=torch.int64, device=self.device)      # [rng call, critic t, actor t]
 
     # ------------------------------------------------------------------ acting
     def select_action(self, state, policy, cuda=False):
@@ -232,11 +243,57 @@ class MOBODY(object):
             raise NotImplementedError("rollout_from_src=1 needs the DARA classifier (not on the accelerated path yet)")
 
     # ------------------------------------------------------------------ training
+    # ------------------------------------------------------------------ HIP-graph fast path
+    def _graph_ok(self, writer):
+        d = torch.distributed
+        return (self.use_graph and self.rng == "device" and self.penalty_type not in ("par", "dara")
+                and not self.config["advantage"] and (self.total_it - 1) % REFRESH_EVERY != 0
+                and not (writer is not None and self.total_it % 5000 == 0)
+                and not (d.is_available() and d.is_initialized() and d.get_world_size() > 1))
+
+    def _graph_body(self, src, tar, batch_size):
+        cfg, S, A = self.config, self.S, self.A
+        ns, nt = int(cfg["src_ratio"] * batch_size), int(cfg["trg_ratio"] * batch_size)
+        nf = int(cfg["fake_batch_scale"] * batch_size) if cfg["fake_batch_scale"] != 0 else 0
+        N, Nt = ns + nt + nf, ns + nt
+        c = self._ctr
+        ops.counter_add(c[0:1]); ops.counter_add(c[1:2]); ops.counter_add(c[2:3])
+        bufs, idx = [src, tar], [ops.sample_indices(self.seed + 101, 3, c[0:1], 0, ns, src.ptr_size[1:2]),
+                                 ops.sample_indices(self.seed + 102, 3, c[0:1], 0, nt, tar.ptr_size[1:2])]
+        if nf > 0:
+            fb = self.fake_replay_buffer
+            bufs.append(fb); idx.append(ops.sample_indices(self.seed + 103, 3, c[0:1], 0, nf, fb.ptr_size[1:2]))
+        ops.gather_batch([b._fields() for b in bufs], idx, S, A, out=self._batch)
+        b = self._batch
+        self.critic_grad(b, N, Nt, N, Nt)
+        self.q_optimizer.step_dev(c[1:2], target=self.target_q_funcs, tau=self.tau)
+        self.actor_stats(b, N, Nt, N, Nt)
+        self.actor_grad(b, N, Nt, N, Nt)
+        self.policy_optimizer.step_dev(c[2:3])
+
+    def _graph_step(self, src, tar, batch_size):
+        key = (batch_size, id(src), id(tar), src.state.data_ptr(), tar.state.data_ptr())
+        if self._graph is None or self._graph_key != key:
+            torch.cuda.synchronize()
+            self._ctr[1] = self.q_optimizer.t
+            self._ctr[2] = self.policy_optimizer.t
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._graph_body(src, tar, batch_size)
+            self._graph, self._graph_key = g, key
+        self._graph.replay()
+        self.q_optimizer.t += 1
+        self.policy_optimizer.t += 1
+
     def train(self, src_replay_buffer, tar_replay_buffer, batch_size=128, writer=None, wandbrun=None):
         """One gradient step, mobody.py:347-578."""
         cfg = self.config
         self.total_it += 1
         self.src_replay_buffer, self.tar_replay_buffer = src_replay_buffer, tar_replay_buffer
+        if self._batch is not None and self._graph_ok(writer):
+            return self._graph_step(src_replay_buffer, tar_replay_buffer, batch_size)
+        if self._graph is not None:                       # an eager step (refresh/logging) moves the host-side counts
+            self._graph = None
         if self.penalty_type == "dara":
             raise NotImplementedError("penalty_type='dara' (classifier warm-up, mobody.py:354-381) is not accelerated yet")
         if cfg["advantage"]:

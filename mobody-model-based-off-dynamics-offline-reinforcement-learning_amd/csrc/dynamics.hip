@@ -29,68 +29,72 @@ struct DynFwdArgs {
   int use_trg;
 };
 
+template <int MT>
 __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
+  constexpr int TB = 32 * MT;
   const int e = blockIdx.y;
-  const long long row0 = (long long)blockIdx.x * BM;
-  const int rows_here = (int)min((long long)BM, a.B - row0);
+  const long long row0 = (long long)blockIdx.x * TB;
+  const int rows_here = (int)min((long long)TB, a.B - row0);
   const int S = a.L.S, A = a.L.A;
   const int lane = lane_id(), w = wave_id();
   auto Wp = [&](int l) { return a.blob + a.L.layer[l].w_off + (long long)e * a.L.layer[l].Kp * a.L.layer[l].Np; };
   auto Bp = [&](int l) { return a.blob + a.L.layer[l].b_off + (long long)e * a.L.layer[l].Np; };
 
   // ---- state encoder: zs = mu-half of zs3(Sw(zs2(Sw(zs1(s)))))   (encode_state :217-225) ----
-  tile_load(Xs, 0, a.obs + row0 * S, S, S, 0, rows_here);
-  tile_zero_cols(Xs, S, a.L.layer[MOBODY_DL_ZS1].Kp);
+  tile_load(Xs, 0, a.obs + row0 * S, S, S, 0, rows_here, TB);
+  tile_zero_cols(Xs, S, a.L.layer[MOBODY_DL_ZS1].Kp, TB);
   lds_barrier();
-  wide_layer<ACT_SWISH, 2>(Xs, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, NoExtra{});
-  wide_layer<ACT_SWISH, 2>(Xs, Wp(MOBODY_DL_ZS2), Bp(MOBODY_DL_ZS2), HID, NoExtra{});
+  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, NoExtra{});
+  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS2), Bp(MOBODY_DL_ZS2), HID, NoExtra{});
 
-  // From here to the latent sum every wave works on its own 16 rows: no barriers needed.
-  const int i = lane & 15, q = lane >> 4;
-  float* myrow = Xs + (16 * w + 4 * q) * LDX;       // rows 16w+4q+r, r = 0..3 (C/D map of 16x16 MFMA)
-  f32x4 zs[1];
-  narrow_gemm<1>(Xs, Wp(MOBODY_DL_ZS3), HID, 16, 0, zs);
-  {
-    const float b = Bp(MOBODY_DL_ZS3)[i];
+  // From here to the latent sum every wave works on its own 16 rows: no barriers needed (waves without rows idle).
+  if (16 * w < TB) {
+    const int i = lane & 15, q = lane >> 4;
+    float* myrow = Xs + (16 * w + 4 * q) * LDX;       // rows 16w+4q+r, r = 0..3 (C/D map of 16x16 MFMA)
+    f32x4 zs[1];
+    narrow_gemm<1>(Xs, Wp(MOBODY_DL_ZS3), HID, 16, 0, zs, TB);
+    {
+      const float b = Bp(MOBODY_DL_ZS3)[i];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { zs[0][r] += b; myrow[r * LDX + i] = zs[0][r]; }
-  }
-  // ---- action encoder on [zs, a]   (encode_trg_action :258-271 / encode_src_action :245-256) ----
-  const int la1 = a.use_trg ? MOBODY_DL_ZA_TRG1 : MOBODY_DL_ZA_SRC1;
-  const int la2 = a.use_trg ? MOBODY_DL_ZA_TRG2 : MOBODY_DL_ZA_SRC2;
-  const int Kza = a.L.layer[la1].Kp;
-  for (int idx = lane; idx < 16 * (Kza - LATENT); idx += 64) {
-    const int r = idx / (Kza - LATENT), c = idx - r * (Kza - LATENT);
-    const int row = 16 * w + r;
-    const float v = a.act[(row0 + min(row, rows_here - 1)) * A + min(c, A - 1)];      // unconditional, clamped
-    Xs[row * LDX + LATENT + c] = (c < A && row < rows_here) ? v : 0.f;
-  }
-  f32x4 g[2];
-  narrow_gemm<2>(Xs, Wp(la1), Kza, 32, 0, g);
+      for (int r = 0; r < 4; ++r) { zs[0][r] += b; myrow[r * LDX + i] = zs[0][r]; }
+    }
+    // ---- action encoder on [zs, a]   (encode_trg_action :258-271 / encode_src_action :245-256) ----
+    const int la1 = a.use_trg ? MOBODY_DL_ZA_TRG1 : MOBODY_DL_ZA_SRC1;
+    const int la2 = a.use_trg ? MOBODY_DL_ZA_TRG2 : MOBODY_DL_ZA_SRC2;
+    const int Kza = a.L.layer[la1].Kp;
+    for (int idx = lane; idx < 16 * (Kza - LATENT); idx += 64) {
+      const int r = idx / (Kza - LATENT), c = idx - r * (Kza - LATENT);
+      const int row = 16 * w + r;
+      const float v = a.act[(row0 + min(row, rows_here - 1)) * A + min(c, A - 1)];      // unconditional, clamped
+      Xs[row * LDX + LATENT + c] = (c < A && row < rows_here) ? v : 0.f;
+    }
+    f32x4 g[2];
+    narrow_gemm<2>(Xs, Wp(la1), Kza, 32, 0, g, TB);
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const float b = Bp(la1)[16 * n + i];
+    for (int n = 0; n < 2; ++n) {
+      const float b = Bp(la1)[16 * n + i];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) myrow[r * LDX + 16 * n + i] = activate<ACT_SWISH>(g[n][r] + b);
-  }
-  f32x4 za[1];
-  narrow_gemm<1>(Xs, Wp(la2), 32, 16, 0, za);
-  {
-    const float b = Bp(la2)[i];
+      for (int r = 0; r < 4; ++r) myrow[r * LDX + 16 * n + i] = activate<ACT_SWISH>(g[n][r] + b);
+    }
+    f32x4 za[1];
+    narrow_gemm<1>(Xs, Wp(la2), 32, 16, 0, za, TB);
+    {
+      const float b = Bp(la2)[i];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) myrow[r * LDX + i] = zs[0][r] + za[0][r] + b;     // z_ns = zs + za  (:319,327)
+      for (int r = 0; r < 4; ++r) myrow[r * LDX + i] = zs[0][r] + za[0][r] + b;     // z_ns = zs + za  (:319,327)
+    }
   }
   lds_barrier();
 
   // ---- transition decoder   (encode_transition :287-293) ----
-  wide_layer<ACT_SWISH, 2>(Xs, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, NoExtra{});
-  wide_layer<ACT_SWISH, 2>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, NoExtra{});
+  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, NoExtra{});
+  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, NoExtra{});
   const float* b3 = Bp(MOBODY_DL_TR3);
   float* mean = a.mean + ((long long)e * a.B + row0) * S;
   narrow_layer(Xs, Wp(MOBODY_DL_TR3), HID, a.L.layer[MOBODY_DL_TR3].Np, [&](int row, int col, float v) {
     if (row < rows_here && col < S) mean[row * S + col] = v + b3[col];
-  });
+  }, TB);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -189,19 +193,28 @@ __global__ __launch_bounds__(256) void k_dyn_finalize(DynFinalArgs a) {
   a.reward[b] = (a.coef != 0.f) ? raw - a.coef * a.penalty[b] : raw;       // :261-263
 }
 
-static int launch_dyn_fwd(const float* blob, const MobodyDynLayout& L, const float* obs, const float* act, long long B,
-                          int use_trg, float* mean, hipStream_t st) {
+template <int MT>
+static int launch_dyn_fwd_t(const DynFwdArgs& a, hipStream_t st) {
+  constexpr size_t lds = (size_t)32 * MT * LDX * sizeof(float);
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_dyn_fwd, TILE_LDS_BYTES);
+    int rc = allow_big_lds(k_dyn_fwd<MT>, lds);
     if (rc) return rc;
     once = true;
   }
-  DynFwdArgs a{blob, L, obs, act, mean, B, use_trg};
   ProfScope prof(PROF_DYN_FWD, st);
-  hipLaunchKernelGGL(k_dyn_fwd, dim3((unsigned)cdiv(B, BM), NENS), dim3(NTHREADS), TILE_LDS_BYTES, st, a);
+  hipLaunchKernelGGL(k_dyn_fwd<MT>, dim3((unsigned)cdiv(a.B, 32 * MT), NENS), dim3(NTHREADS), lds, st, a);
   MB_LAUNCH_OK("k_dyn_fwd");
   return 0;
+}
+
+static int launch_dyn_fwd(const float* blob, const MobodyDynLayout& L, const float* obs, const float* act, long long B,
+                          int use_trg, float* mean, hipStream_t st) {
+  DynFwdArgs a{blob, L, obs, act, mean, B, use_trg};
+  // 64-row tiles here: the nine-layer chain has a wave-local narrow section in which a 32-row tile idles half of
+  // the waves (measured 102 vs 88 TFLOP/s at 50 000 rows); MOBODY_DYN_TILE_ROWS=32 selects the short tile.
+  static const bool short_tile = [] { const char* e = getenv("MOBODY_DYN_TILE_ROWS"); return e && atoi(e) == 32; }();
+  return short_tile ? launch_dyn_fwd_t<1>(a, st) : launch_dyn_fwd_t<2>(a, st);
 }
 
 }  // namespace mobody

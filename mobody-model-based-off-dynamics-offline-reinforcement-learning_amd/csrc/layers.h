@@ -4,6 +4,8 @@
 //   the ensemble reward head               (Swish; mobody_module.py:295-302)
 //   the DARA classifier heads              (ReLU;  mobody.py:11-33)
 #pragma once
+#include <stdlib.h>
+
 #include "tile.h"
 
 namespace mobody {
@@ -49,11 +51,14 @@ struct Mlp3FwdArgs {
 
 int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stream);
 
-// Row-tile height for a launch of `rows` x `members`: 32-row tiles when 64-row tiles would leave the 256 CUs
-// (x up to 2 resident 64-row workgroups) under-filled, 64-row tiles (less weight re-streaming from L2) otherwise.
+// Row-tile height of the fused MLP kernels.  Measured on MI355X (bench.py, S=17/A=6): 32-row tiles (33 KB LDS,
+// ~124 VGPRs -> 4 workgroups = 16 waves per CU) beat 64-row tiles (2 workgroups per CU) at every batch size from
+// 2.5 k to 41 k rows (forward 84 vs 73 TFLOP/s at 41 k rows, 60 vs 51 at 10 k): occupancy hides the weight-fetch
+// latency better than the 2x weight reuse of the taller tile.  MOBODY_TILE_ROWS=64 selects the tall tile (tuning aid).
 inline int pick_tile_rows(long long rows, int members) {
-  const long long blocks64 = ((rows + 63) / 64) * members;
-  return blocks64 >= 1024 ? 64 : 32;
+  static const int forced = [] { const char* e = getenv("MOBODY_TILE_ROWS"); return e ? atoi(e) : 0; }();
+  (void)rows; (void)members;
+  return forced == 64 ? 64 : 32;
 }
 
 }  // namespace mobody

@@ -207,9 +207,14 @@ __global__ __launch_bounds__(256) void k_actor_loss(ActorRowArgs a, int nparts) 
 struct AdamConsts { float w1, b2, w2, step_size, bc2_sqrt, eps, tau, one_minus_tau, gscale; };
 
 __global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m, float* v, float* target, long long n,
-                                              AdamConsts c) {
+                                              AdamConsts c, const long long* t_dev, float lr) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
+  if (t_dev != nullptr) {                         // graph replay: the step count lives in device memory
+    const double t = (double)t_dev[0];
+    c.step_size = (float)((double)lr / (1.0 - pow(0.9, t)));
+    c.bc2_sqrt = (float)sqrt(1.0 - pow(0.999, t));
+  }
   const float gj = g[j] * c.gscale;
   const float m0 = m[j];
   const float mj = m0 + c.w1 * (gj - m0);
@@ -407,16 +412,17 @@ extern "C" int mobody_mlp_transpose(int in_dim, int out_dim, int members, const 
   return 0;
 }
 
-extern "C" int mobody_adam_polyak(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad,
-                                  float* m, float* v, float* target, int64_t t, float lr, float tau, float grad_scale,
-                                  void* stream) {
+static int adam_impl(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad, float* m,
+                     float* v, float* target, int64_t t, const int64_t* t_dev, float lr, float tau, float grad_scale,
+                     void* stream) {
   MobodyMlpLayout L;
   int rc = mobody_mlp_layout(in_dim, out_dim, members, &L);
   if (rc) return rc;
   MB_REQUIRE(blob && grad && m && v, "mobody_adam_polyak: null pointer");
-  MB_REQUIRE(t >= 1, "mobody_adam_polyak: step t must be >= 1");
+  MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_adam_polyak: step t must be >= 1");
   // torch.optim.Adam scalar bookkeeping in double, as the reference's host code does
-  const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
+  const double tt = t_dev ? 1.0 : (double)t;
+  const double bc1 = 1.0 - pow(0.9, tt), bc2 = 1.0 - pow(0.999, tt);
   AdamConsts c;
   c.w1 = (float)(1.0 - 0.9); c.b2 = (float)0.999; c.w2 = (float)(1.0 - 0.999);
   c.step_size = (float)((double)lr / bc1); c.bc2_sqrt = (float)sqrt(bc2); c.eps = 1e-8f;
@@ -424,10 +430,23 @@ extern "C" int mobody_adam_polyak(int in_dim, int out_dim, int members, float* b
   float* tgt = (target != nullptr && tau >= 0.f) ? target : nullptr;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)cdiv(L.total_floats, 256)), dim3(256), 0, st, blob, grad, m, v, tgt,
-                     (long long)L.total_floats, c);
+                     (long long)L.total_floats, c, (const long long*)t_dev, lr);
   MB_LAUNCH_OK("k_adam");
   if (blob_T != nullptr) return mobody_mlp_transpose(in_dim, out_dim, members, blob, blob_T, stream);
   return 0;
+}
+
+extern "C" int mobody_adam_polyak(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad,
+                                  float* m, float* v, float* target, int64_t t, float lr, float tau, float grad_scale,
+                                  void* stream) {
+  return adam_impl(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t, nullptr, lr, tau, grad_scale, stream);
+}
+
+extern "C" int mobody_adam_polyak_dev(int in_dim, int out_dim, int members, float* blob, float* blob_T,
+                                      const float* grad, float* m, float* v, float* target, const int64_t* t_dev,
+                                      float lr, float tau, float grad_scale, void* stream) {
+  MB_REQUIRE(t_dev != nullptr, "mobody_adam_polyak_dev: t_dev is null");
+  return adam_impl(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, 0, t_dev, lr, tau, grad_scale, stream);
 }
 
 // ---- PAR reward penalty: r -= coef * mean_d (s'_true - s'_model)^2   (mobody.py:428-434) ----

@@ -210,3 +210,9 @@ def par_penalty(next_state_true, next_state_model, reward, coef):
     n, S = next_state_true.shape
     check(load().mobody_par_penalty(ptr(next_state_true), ptr(next_state_model), ptr(reward), float(coef), n, S,
                                     cur_stream()), "mobody_par_penalty")
+
+
+def adam_polyak_dev(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t_dev, lr, tau=-1.0, grad_scale=1.0):
+    check(load().mobody_adam_polyak_dev(in_dim, out_dim, members, ptr(blob), ptr(blob_T), ptr(grad), ptr(m), ptr(v),
+                                        ptr(target), ptr(t_dev), float(lr), float(tau), float(grad_scale),
+                                        cur_stream()), "mobody_adam_polyak_dev")
