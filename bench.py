@@ -75,7 +75,7 @@ def prof_pass(pol, src, tar, bs, steps):
     Runs eagerly (event records are not part of a captured graph); the kernels are the same."""
     from mobody_amd import _lib
     lib = _lib.load()
-    pol.use_graph = False
+    pol.use_graph = 0
     _lib.check(lib.mobody_prof_begin(steps * 64), "prof_begin")
     for _ in range(steps):
         pol.train(src, tar, bs, None, None)
@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch_size", type=int, default=BS)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--graph", type=int, default=1, help="replay the steady-state step as a captured HIP graph (1 GPU only)")
+    ap.add_argument("--graph", type=int, default=2, help="HIP-graph replay of the steady-state step: 0 never, 1 always, 2 auto (minibatches under 4096 rows); 1 GPU only")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -212,7 +212,7 @@ def main():
             "config": {"workload": f"walker2d-friction shapes S={S} A={A}, ensemble 7, rollout_len 1, batch_size {bs}/GPU "
                                    f"(N={N} rows per train() step: src|tar|fake = {bs}|{bs}|{bs // 2}), fp32 MFMA",
                        "rows_per_step_per_gpu": N, "parallelism": f"dp{world}",
-                       "hip_graph": bool(args.graph and world == 1)},
+                       "hip_graph": bool(world == 1 and (args.graph == 1 or (args.graph == 2 and N < 4096)))},
             "grad_steps_per_sec": args.steps / dt,
             "rollout_transitions_per_sec": roll_rate, "rollout_ms_per_50000": roll_ms,
             "rollout_refresh_amortised_ms_per_step": (152000.0 / roll_rate) * 1e3 / 5000.0,

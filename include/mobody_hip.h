@@ -161,6 +161,16 @@ int mobody_gather_batch(const MobodyBufferView* bufs, const int32_t* const* idx,
                         int S, int A, float* state, float* action, float* next_state, float* reward, float* not_done,
                         void* stream);
 
+/* Same gather with the row indices drawn on the device (np.random.randint(0, size, n), utils.py:128, throughput
+ * mode): index i of source k = philox(seeds[k], stream 3, call)[i] * size >> 32 with
+ * call = (counter ? counter[0] : 0) + call_offsets[k] and size read from the DEVICE word sizes[k][0]
+ * (`seeds`, `call_offsets`, `counts` and the `sizes` pointer array are host arrays).  Identical draws to
+ * mobody_rng_index / mobody_sample_indices for the same (seed, call). */
+int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64_t* counts, int nbuf, int S, int A,
+                            const uint32_t* seeds, const int64_t* call_offsets, const int64_t* counter,
+                            const int64_t* const* sizes, float* state, float* action, float* next_state,
+                            float* reward, float* not_done, void* stream);
+
 /* Append the rows with keep[i] != 0 (NULL = all), in order, to a ring buffer of `cap` rows at
  * *ptr_size (device int64[2] = {ptr, size}), reproducing add_batch's single-wrap arithmetic
  * (utils.py:43-92); not_done = 1 - terminal.  `scan_ws` needs (M + 1024) int32. */

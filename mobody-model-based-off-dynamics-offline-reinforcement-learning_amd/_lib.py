@@ -70,6 +70,8 @@ PROTOTYPES = {
                                       vp, vp, vp, vp]),
     "mobody_gather_batch": (C.c_int, [C.POINTER(MobodyBufferView), C.POINTER(vp), C.POINTER(i64), C.c_int, C.c_int,
                                       C.c_int, vp, vp, vp, vp, vp, vp]),
+    "mobody_gather_batch_rng": (C.c_int, [C.POINTER(MobodyBufferView), C.POINTER(i64), C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(u32), C.POINTER(i64), vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp]),
     "mobody_ring_append": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, vp,
                                      vp]),
     "mobody_train_workspace": (i64, [C.POINTER(MobodyTrainDims)]),

@@ -157,7 +157,8 @@ class MOBODY(object):
         self.last_losses = None
         # HIP-graph replay of the steady-state step (config['graph']=1, rng='device', single GPU, no PAR/DARA):
         # all per-step scalars (RNG call id, Adam step counts, buffer sizes) live in device words.
-        self.use_graph = bool(config.get("graph", 0))
+        # config['graph']: 0 never, 1 always, 2 auto (replay pays off for launch-bound steps, i.e. small minibatches)
+        self.use_graph = int(config.get("graph", 0))
         self._graph, self._graph_key = None, None
         self._ctr = torch.zeros(3, dtype=torch.int64, device=self.device)      # [rng call, critic t, actor t]
 
@@ -246,7 +247,8 @@ class MOBODY(object):
     # ------------------------------------------------------------------ HIP-graph fast path
     def _graph_ok(self, writer):
         d = torch.distributed
-        return (self.use_graph and self.rng == "device" and self.penalty_type not in ("par", "dara")
+        want = self.use_graph == 1 or (self.use_graph == 2 and self._batch[0].shape[0] < 4096)
+        return (want and self.rng == "device" and self.penalty_type not in ("par", "dara")
                 and not self.config["advantage"] and (self.total_it - 1) % REFRESH_EVERY != 0
                 and not (writer is not None and self.total_it % 5000 == 0)
                 and not (d.is_available() and d.is_initialized() and d.get_world_size() > 1))
@@ -258,12 +260,11 @@ class MOBODY(object):
         N, Nt = ns + nt + nf, ns + nt
         c = self._ctr
         ops.counter_add(c[0:1]); ops.counter_add(c[1:2]); ops.counter_add(c[2:3])
-        bufs, idx = [src, tar], [ops.sample_indices(self.seed + 101, 3, c[0:1], 0, ns, src.ptr_size[1:2]),
-                                 ops.sample_indices(self.seed + 102, 3, c[0:1], 0, nt, tar.ptr_size[1:2])]
+        bufs, cnts, seeds = [src, tar], [ns, nt], [self.seed + 101, self.seed + 102]
         if nf > 0:
-            fb = self.fake_replay_buffer
-            bufs.append(fb); idx.append(ops.sample_indices(self.seed + 103, 3, c[0:1], 0, nf, fb.ptr_size[1:2]))
-        ops.gather_batch([b._fields() for b in bufs], idx, S, A, out=self._batch)
+            bufs.append(self.fake_replay_buffer); cnts.append(nf); seeds.append(self.seed + 103)
+        ops.gather_batch_rng([b._fields() for b in bufs], cnts, seeds, [0] * len(bufs), c[0:1],
+                             [b.ptr_size[1:2] for b in bufs], S, A, self._batch)
         b = self._batch
         self.critic_grad(b, N, Nt, N, Nt)
         self.q_optimizer.step_dev(c[1:2], target=self.target_q_funcs, tau=self.tau)
@@ -309,18 +310,14 @@ class MOBODY(object):
             self._batch_key = (N,)
         b = self._batch
         # src | tar rows (mobody.py:399-400); index draws in the reference's order
-        s_idx = src_replay_buffer.draw_indices(ns)
-        t_idx = tar_replay_buffer.draw_indices(nt)
-        ops.gather_batch([src_replay_buffer._fields(), tar_replay_buffer._fields()], [s_idx, t_idx], S, A,
-                         out=tuple(t[:Nt] for t in b))
+        self._gather([src_replay_buffer, tar_replay_buffer], [ns, nt], tuple(t[:Nt] for t in b))
         if self.penalty_type == "par":                                        # :428-434
             r = self.dynamics.step_device(b[0][:ns], b[1][:ns])
             ops.par_penalty(b[2][:ns], r["next_obs"], b[3][:ns], cfg["penalty_coef"])
         if (self.total_it - 1) % REFRESH_EVERY == 0:
             self._refresh(src_replay_buffer, tar_replay_buffer)
         if nf > 0:                                                            # :523-529
-            f_idx = self.fake_replay_buffer.draw_indices(nf)
-            ops.gather_batch([self.fake_replay_buffer._fields()], [f_idx], S, A, out=tuple(t[Nt:] for t in b))
+            self._gather([self.fake_replay_buffer], [nf], tuple(t[Nt:] for t in b))
         self._update(b, N, Nt)
         if writer is not None and self.total_it % 5000 == 0:
             q_loss, pi_loss, bc_loss = [float(x) for x in self._loss[:3].tolist()]
@@ -329,6 +326,20 @@ class MOBODY(object):
             writer.add_scalar("train/bc_loss", bc_loss, self.total_it)
             if wandbrun is not None:
                 wandbrun.log({"train/policy_loss": pi_loss, "train/q_loss": q_loss}, step=self.total_it)
+
+    def _gather(self, bufs, counts, out):
+        """Minibatch rows of `bufs` into `out`: NumPy index stream + gather (rng='numpy'), or one kernel that draws
+        the same indices `ReplayBuffer.draw_indices` would on the device (rng='device')."""
+        if self.rng == "device":
+            for rb in bufs:
+                if rb.size <= 0:
+                    raise ValueError("low >= high")               # np.random.randint(0, 0) in the reference (Q11)
+                rb._draws += 1
+            ops.gather_batch_rng([rb._fields() for rb in bufs], counts, [rb.seed for rb in bufs],
+                                 [rb._draws for rb in bufs], None, [rb.ptr_size[1:2] for rb in bufs], self.S, self.A, out)
+        else:
+            idx = [rb.draw_indices(n) for rb, n in zip(bufs, counts)]
+            ops.gather_batch([rb._fields() for rb in bufs], idx, self.S, self.A, out=out)
 
     def _update(self, b, N, Nt):
         """critic step -> Adam+Polyak -> actor forward -> (stats all-reduce) -> actor backward -> Adam

@@ -5,15 +5,22 @@
 //                   into the ring with add_batch's single-wrap arithmetic (utils.py:43-92);
 //                   three small kernels: per-block scan, scan of block totals, scatter (+ ptr/size update).
 #include "common.h"
+#include "rng.h"
 
 namespace mobody {
 
 struct GatherArgs {
   MobodyBufferView bufs[3];
-  const int32_t* idx[3];
+  const int32_t* idx[3];    // explicit row indices, or null -> drawn on the fly from the device generator
   long long start[4];       // row offsets of each source inside the output, start[nbuf] = N
   int nbuf, S, A;
   float *state, *action, *next_state, *reward, *not_done;
+  // device-RNG mode (idx[k] == null): index i of source k = philox(seed[k], STREAM_SAMPLE, call)[i] * size >> 32,
+  // call = (counter ? counter[0] : 0) + call_offset[k], size read from the device word size[k][0]
+  uint32_t seed[3];
+  long long call_offset[3];
+  const long long* counter;
+  const long long* size[3];
 };
 
 __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
@@ -26,7 +33,14 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
   int k = 0;
   if (a.nbuf > 1 && row >= a.start[1]) k = 1;
   if (a.nbuf > 2 && row >= a.start[2]) k = 2;
-  const long long src = a.idx[k][row - a.start[k]];
+  long long src;
+  if (a.idx[k] != nullptr) {
+    src = a.idx[k][row - a.start[k]];
+  } else {
+    const uint32_t call = (uint32_t)((a.counter ? a.counter[0] : 0) + a.call_offset[k]);
+    const long long sz = a.size[k][0];
+    src = rng_index_at(a.seed[k], STREAM_SAMPLE, call, (uint64_t)(row - a.start[k]), (uint32_t)(sz > 0 ? sz : 1));
+  }
   const int S = a.S, A = a.A;
   if (c < S) a.state[row * S + c] = a.bufs[k].state[src * S + c];
   else if (c < S + A) a.action[row * A + (c - S)] = a.bufs[k].action[src * A + (c - S)];
@@ -170,5 +184,30 @@ extern "C" int mobody_ring_append(float* b_state, float* b_action, float* b_next
   MB_LAUNCH_OK("k_ring_scatter");
   hipLaunchKernelGGL(k_ring_commit, dim3(1), dim3(1), 0, st, (long long*)ptr_size, (long long)cap, tops, nblocks);
   MB_LAUNCH_OK("k_ring_commit");
+  return 0;
+}
+
+extern "C" int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64_t* counts, int nbuf, int S, int A,
+                                       const uint32_t* seeds, const int64_t* call_offsets, const int64_t* counter,
+                                       const int64_t* const* sizes, float* state, float* action, float* next_state,
+                                       float* reward, float* not_done, void* stream) {
+  MB_REQUIRE(bufs && counts && seeds && call_offsets && sizes && nbuf >= 1 && nbuf <= 3, "mobody_gather_batch_rng: need 1..3 source buffers");
+  MB_REQUIRE(S >= 1 && A >= 1, "mobody_gather_batch_rng: bad dims");
+  GatherArgs a{};
+  long long N = 0;
+  for (int k = 0; k < nbuf; ++k) {
+    MB_REQUIRE(counts[k] >= 0, "mobody_gather_batch_rng: negative count");
+    MB_REQUIRE(counts[k] == 0 || (sizes[k] && bufs[k].state && bufs[k].action && bufs[k].next_state && bufs[k].reward && bufs[k].not_done),
+               "mobody_gather_batch_rng: null pointer in source %d", k);
+    a.bufs[k] = bufs[k]; a.idx[k] = nullptr; a.start[k] = N; N += counts[k];
+    a.seed[k] = seeds[k]; a.call_offset[k] = call_offsets[k]; a.size[k] = (const long long*)sizes[k];
+  }
+  a.start[nbuf] = N; a.nbuf = nbuf; a.S = S; a.A = A; a.counter = (const long long*)counter;
+  if (N == 0) return 0;
+  MB_REQUIRE(state && action && next_state && reward && not_done, "mobody_gather_batch_rng: null output");
+  a.state = state; a.action = action; a.next_state = next_state; a.reward = reward; a.not_done = not_done;
+  const long long total = N * (2 * S + A + 2);
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream), a);
+  MB_LAUNCH_OK("k_gather");
   return 0;
 }

@@ -206,8 +206,29 @@ __global__ __launch_bounds__(256) void k_actor_loss(ActorRowArgs a, int nparts) 
 // on the host and rounded to fp32 once, as torch does when it multiplies a fp32 tensor by a Python float.
 struct AdamConsts { float w1, b2, w2, step_size, bc2_sqrt, eps, tau, one_minus_tau, gscale; };
 
+// Destination of parameter entry (member-local offset o) inside the member's T blob, or -1 (biases, padding rows).
+__device__ __forceinline__ long long t_blob_index(const MobodyMlpLayout& L, long long o) {
+  if (o < L.b1) {                                   // W1 (wide storage): W1T[n][k] row major, ld = Np1t
+    const long long g = o >> 2;
+    const int k = (int)(g / HID) * 4 + (int)(o & 3), n = (int)(g % HID);
+    return L.w1t + (long long)n * L.Np1t + k;
+  }
+  if (o >= L.w2 && o < L.b2) {                      // W2 (wide): W2T[n][k] wide
+    const long long oo = o - L.w2, g = oo >> 2;
+    const int k = (int)(g / HID) * 4 + (int)(oo & 3), n = (int)(g % HID);
+    return L.w2t + wide_idx(n, k);
+  }
+  if (o >= L.w3 && o < L.b3) {                      // W3 (narrow [256][Np3]): W3T[n3][k] wide
+    const long long oo = o - L.w3;
+    const int k = (int)(oo / L.Np3), n3 = (int)(oo % L.Np3);
+    return L.w3t + wide_idx(n3, k);
+  }
+  return -1;
+}
+
 __global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m, float* v, float* target, long long n,
-                                              AdamConsts c, const long long* t_dev, float lr) {
+                                              AdamConsts c, const long long* t_dev, float lr, MobodyMlpLayout L,
+                                              float* blob_T) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   if (t_dev != nullptr) {                         // graph replay: the step count lives in device memory
@@ -223,6 +244,11 @@ __global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m
   const float pj = p[j] - c.step_size * (mj / (sqrtf(vj) / c.bc2_sqrt + c.eps));
   p[j] = pj;
   if (target != nullptr) target[j] = c.tau * pj + c.one_minus_tau * target[j];      // update_target :183-187
+  if (blob_T != nullptr) {                          // keep the transposes the backward kernels stream in sync
+    const int mem = (int)(j / L.member_floats);
+    const long long ti = t_blob_index(L, j - (long long)mem * L.member_floats);
+    if (ti >= 0) blob_T[(long long)mem * L.t_member_floats + ti] = pj;
+  }
 }
 
 // W1 and W2 (and W3T, W2T of the T blob) are 256 columns wide and stored K-interleaved (tile.h wide_idx);
@@ -430,10 +456,9 @@ static int adam_impl(int in_dim, int out_dim, int members, float* blob, float* b
   float* tgt = (target != nullptr && tau >= 0.f) ? target : nullptr;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)cdiv(L.total_floats, 256)), dim3(256), 0, st, blob, grad, m, v, tgt,
-                     (long long)L.total_floats, c, (const long long*)t_dev, lr);
+                     (long long)L.total_floats, c, (const long long*)t_dev, lr, L, blob_T);
   MB_LAUNCH_OK("k_adam");
-  if (blob_T != nullptr) return mobody_mlp_transpose(in_dim, out_dim, members, blob, blob_T, stream);
-  return 0;
+  return 0;       // (W1T's zero padding columns k >= Kp1 are written once by mobody_mlp_transpose and never change)
 }
 
 extern "C" int mobody_adam_polyak(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad,

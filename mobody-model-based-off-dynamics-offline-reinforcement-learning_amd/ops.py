@@ -216,3 +216,17 @@ def adam_polyak_dev(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, 
     check(load().mobody_adam_polyak_dev(in_dim, out_dim, members, ptr(blob), ptr(blob_T), ptr(grad), ptr(m), ptr(v),
                                         ptr(target), ptr(t_dev), float(lr), float(tau), float(grad_scale),
                                         cur_stream()), "mobody_adam_polyak_dev")
+
+
+def gather_batch_rng(buffers, counts, seeds, call_offsets, counter, sizes, S, A, out):
+    """Gather with device-drawn indices: buffers = list of 5-tuples, sizes = list of device int64[1] views,
+    counter = device int64[1] or None.  `out` = (state, action, next_state, reward, not_done) destination tensors."""
+    n = len(buffers)
+    views = (_lib.MobodyBufferView * n)(*[_lib.MobodyBufferView(*[ptr(t) for t in b]) for b in buffers])
+    cnt = (C.c_int64 * n)(*[int(c) for c in counts])
+    sd = (C.c_uint32 * n)(*[int(s) & 0xFFFFFFFF for s in seeds])
+    off = (C.c_int64 * n)(*[int(o) for o in call_offsets])
+    sz = (C.c_void_p * n)(*[ptr(s) for s in sizes])
+    check(load().mobody_gather_batch_rng(views, cnt, n, S, A, sd, off, ptr(counter), sz, *[ptr(t) for t in out],
+                                         cur_stream()), "mobody_gather_batch_rng")
+    return out
