@@ -231,6 +231,29 @@ int mobody_adam_polyak_dev(int in_dim, int out_dim, int members, float* blob, fl
 int mobody_par_penalty(const float* next_state_true, const float* next_state_model, float* reward, float coef,
                        int64_t n, int S, void* stream);
 
+/* ---- generic gradient of one packed MLP + DARA classifier pieces (mobody.py:11-33,146-181,354-381) ---- */
+/* grad (parameter-blob layout) from dz3[members][rows][Np3] and the activations mobody_mlp3_forward saved. */
+int64_t mobody_mlp3_backward_workspace(int in_dim, int out_dim, int members, int64_t rows);
+int mobody_mlp3_backward(const float* blob_T, int in_dim, int out_dim, int members, const float* dz3, const float* x,
+                         const float* h1, const float* h2, int64_t rows, float* grad, float* workspace, void* stream);
+
+/* Classifier inputs x_sas[N][2S+A] = [s,a,s'] + std*eps, x_sa[N][S+A] = [s,a] + std*eps' (eps explicit or device
+ * Philox streams 4/5 at (seed, call); std = 0 -> no noise). */
+int mobody_dara_inputs(const float* s, const float* a, const float* s2, int64_t N, int S, int A, float std,
+                       const float* noise_sas, const float* noise_sa, uint32_t seed, uint32_t call, float* x_sas,
+                       float* x_sa, void* stream);
+
+/* loss_out = (loss_sa, loss_sas) = mean cross_entropy(softmax(logits), label) with the reference's double softmax;
+ * dz_*[N][16] = d(loss)/d(logits) (columns 2..15 zero).  labels NULL -> rows < n_src are 0, the rest 1.
+ * lossp_ws: 2*ceil(N/256) floats. */
+int mobody_dara_loss_grad(const float* z_sas, const float* z_sa, const int32_t* labels, int64_t N, int64_t n_src,
+                          float* dz_sas, float* dz_sa, float* loss_out, float* lossp_ws, void* stream);
+
+/* delta = clamp(log p~_sas[1] - log p~_sa[1] - log p~_sas[0] + log p~_sa[0], -10, 10), p~ = softmax(softmax(logits)) + 1e-10;
+ * reward[i] += coef * delta (reward may be NULL), delta_out optional. */
+int mobody_dara_penalty(const float* z_sas, const float* z_sa, int64_t n, float coef, float* reward, float* delta_out,
+                        void* stream);
+
 /* (Re)build the transposed blob from a parameter blob (after loading a checkpoint). */
 int mobody_mlp_transpose(int in_dim, int out_dim, int members, const float* blob, float* blob_T, void* stream);
 

@@ -84,6 +84,11 @@ PROTOTYPES = {
     "mobody_adam_polyak": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp]),
     "mobody_adam_polyak_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "mobody_par_penalty": (C.c_int, [vp, vp, vp, f32, i64, C.c_int, vp]),
+    "mobody_mlp3_backward_workspace": (i64, [C.c_int, C.c_int, C.c_int, i64]),
+    "mobody_mlp3_backward": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, i64, vp, vp, vp]),
+    "mobody_dara_inputs": (C.c_int, [vp, vp, vp, i64, C.c_int, C.c_int, f32, vp, vp, u32, u32, vp, vp, vp]),
+    "mobody_dara_loss_grad": (C.c_int, [vp, vp, vp, i64, i64, vp, vp, vp, vp, vp]),
+    "mobody_dara_penalty": (C.c_int, [vp, vp, i64, f32, vp, vp, vp]),
     "mobody_mlp_transpose": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp]),
 }
 

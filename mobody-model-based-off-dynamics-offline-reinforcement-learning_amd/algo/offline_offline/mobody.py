@@ -12,8 +12,7 @@ per-rank minibatch is `batch_size` rows per buffer, gradients are all-reduced (R
 blobs per step and the two batch statistics of the actor loss as one 2-float message, so the
 N-GPU update equals the 1-GPU update on the concatenated batch.
 
-Not implemented on this path yet (raise NotImplementedError): penalty_type='dara' classifier warm-up,
-`advantage=1` (V-function variant), `rollout_from_src=1`.
+Not implemented on this path yet (raises NotImplementedError): `advantage=1` (V-function variant).
 """
 import numpy as np
 import torch
@@ -127,6 +126,41 @@ class _Adam(object):
         self.t = int(float(st[0]["step"]))
 
 
+class _Classifier(object):
+    """Domain classifier (mobody.py:11-33): two packed MLPs `sa_classifier` (S+A -> 2) and `sas_classifier`
+    (2S+A -> 2) whose heads output softmax probabilities.  Training and the reward-penalty sweep run through the
+    HIP kernels (csrc/dara.hip); `__call__` exists for API compatibility with `Classifier.forward`."""
+
+    def __init__(self, S, A, device, gaussian_noise_std, lr):
+        self.S, self.A, self.device = S, A, device
+        self.action_dim, self.gaussian_noise_std = A, float(gaussian_noise_std)
+        self.sa_classifier = _PackedNet(S + A, 2, 1, ("sa_classifier.",), device)
+        self.sas_classifier = _PackedNet(2 * S + A, 2, 1, ("sas_classifier.",), device)
+        self.opt_sa, self.opt_sas = _Adam(self.sa_classifier, lr), _Adam(self.sas_classifier, lr)
+        self._calls = 0
+
+    def logits(self, s, a, s2, with_noise, noise_sas=None, noise_sa=None, seed=0, save=False):
+        self._calls += 1
+        std = self.gaussian_noise_std if with_noise else 0.0
+        x_sas, x_sa = ops.dara_inputs(s, a, s2, std, noise_sas, noise_sa, seed, self._calls)
+        f = lambda net, x: ops.mlp3_forward(net.blob, net.in_dim, 2, 1, x, save=save)
+        return f(self.sas_classifier, x_sas), f(self.sa_classifier, x_sa)
+
+    def __call__(self, state_batch, action_batch, nextstate_batch, with_noise):
+        zs, za = self.logits(state_batch, action_batch, nextstate_batch, with_noise)
+        return torch.softmax(zs[0], 1), torch.softmax(za[0], 1)      # API-compat only; the training path never calls this
+
+    def state_dict(self):
+        return {**self.sa_classifier.state_dict(), **self.sas_classifier.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.sa_classifier.load_state_dict({k: v for k, v in sd.items() if k.startswith("sa_classifier.")})
+        self.sas_classifier.load_state_dict({k: v for k, v in sd.items() if k.startswith("sas_classifier.")})
+
+    def parameters(self):
+        return self.sa_classifier.parameters() + self.sas_classifier.parameters()
+
+
 class MOBODY(object):
     def __init__(self, config, device, target_entropy=None):
         self.config = config
@@ -149,6 +183,7 @@ class MOBODY(object):
         self.policy = _PackedNet(S, A, 1, ("network.",), self.device, out_mode=1, max_action=config["max_action"])
         self.q_optimizer = _Adam(self.q_funcs, config["critic_lr"])
         self.policy_optimizer = _Adam(self.policy, config["actor_lr"])
+        self.classifier = _Classifier(S, A, self.device, config["gaussian_noise_std"], config["actor_lr"])
         self.dynamics = None
         self._ws, self._ws_key = None, None
         self._loss = torch.zeros(4, dtype=torch.float32, device=self.device)
@@ -168,6 +203,55 @@ class MOBODY(object):
         x = state if isinstance(state, torch.Tensor) else torch.as_tensor(np.asarray(state), dtype=torch.float32)
         action = policy(x.reshape(-1, self.S).to(self.device))
         return action.squeeze() if cuda else action.squeeze().cpu().numpy()
+
+    # ------------------------------------------------------------------ DARA classifier (mobody.py:146-181, 354-381)
+    def update_classifier(self, src_replay_buffer, tar_replay_buffer, batch_size, writer=None, noise=None, labels=None,
+                          rows=None):
+        """One classifier step: rows = src(bs) | tar(bs) with labels 0 | 1 (the reference also permutes the rows; the
+        loss is a mean over rows and the input noise is iid, so the permutation is dropped).  `rows`/`labels`/`noise`
+        let tests supply the reference's exact permuted batch and noise."""
+        cls = self.classifier
+        if rows is None:
+            bufs = [src_replay_buffer]
+            counts = [batch_size]
+            n_tar = batch_size
+            if self.config["penalize_fake"] and self.fake_replay_buffer.size > 0:       # :149-154
+                bufs.append(self.fake_replay_buffer); counts.append(batch_size); n_tar = 2 * batch_size
+            bufs.append(tar_replay_buffer); counts.append(n_tar)
+            N = sum(counts)
+            out = (torch.empty(N, self.S, device=self.device), torch.empty(N, self.A, device=self.device),
+                   torch.empty(N, self.S, device=self.device), torch.empty(N, 1, device=self.device),
+                   torch.empty(N, 1, device=self.device))
+            self._gather(bufs, counts, out)
+            s, a, s2 = out[0], out[1], out[2]
+            n_src = N - n_tar
+        else:
+            s, a, s2 = rows
+            n_src = s.shape[0] // 2
+        nz = noise or (None, None)
+        (z_sas, x_sas, h1s, h2s), (z_sa, x_sa, h1a, h2a) = cls.logits(s, a, s2, True, nz[0], nz[1], seed=self.seed + 31,
+                                                                    save=True)
+        dz_sas, dz_sa, loss = ops.dara_loss_grad(z_sas[0], z_sa[0], n_src, labels)
+        for net, opt, dz, x, h1, h2 in ((cls.sas_classifier, cls.opt_sas, dz_sas, x_sas, h1s, h2s),
+                                        (cls.sa_classifier, cls.opt_sa, dz_sa, x_sa, h1a, h2a)):
+            self._cls_ws = ops.mlp3_backward(net.blob_T, net.in_dim, 2, 1, dz, x, h1, h2, opt.grad,
+                                             getattr(self, "_cls_ws", None))
+            opt.step()
+        return loss[0], loss[1]                           # (loss_sa, loss_sas) as device scalars
+
+    def _dara_delta(self, s, a, s2, reward=None, coef=0.0):
+        """Noise-free classifier pass + the DARC/DARA log-ratio penalty; adds coef*delta to `reward` in place."""
+        z_sas, z_sa = self.classifier.logits(s, a, s2, False)
+        return ops.dara_penalty(z_sas[0], z_sa[0], coef, reward, want_delta=reward is None)
+
+    def _dara_warmup(self, src_replay_buffer, tar_replay_buffer, batch_size, writer):
+        for _ in range(10 * 500):                                                        # :356
+            self.update_classifier(src_replay_buffer, tar_replay_buffer, batch_size, writer)
+        n, chunk = src_replay_buffer.size, 1 << 16                                       # reference sweeps 1000 rows at a time
+        for i in range(0, n, chunk):
+            j = min(n, i + chunk)
+            self._dara_delta(src_replay_buffer.state[i:j], src_replay_buffer.action[i:j], src_replay_buffer.next_state[i:j],
+                             src_replay_buffer.reward[i:j], self.config["penalty_coef"])
 
     # ------------------------------------------------------------------ rollouts
     def rollout(self, init_obss, rollout_length, use_trg=True):
@@ -240,8 +324,17 @@ class MOBODY(object):
             keep = (r["penalty"] < cfg["env_filter"]).to(torch.uint8).squeeze(1)
             self.fake_replay_buffer.add_batch(dict(obss=src[0], next_obss=r["next_obs"], actions=src[1],
                                                    rewards=r["reward"], terminals=r["terminal"]), keep=keep)
-        if cfg["rollout_from_src"]:
-            raise NotImplementedError("rollout_from_src=1 needs the DARA classifier (not on the accelerated path yet)")
+        if cfg["rollout_from_src"]:                                           # :479-513
+            if self.penalty_type != "dara":
+                self.update_classifier(src_rb, tar_rb, cfg.get("batch_size", 128))
+            s_idx = src_rb.draw_indices(REFRESH_SRC)
+            t_idx = tar_rb.draw_indices(100)
+            init = ops.gather_batch([src_rb._fields(), tar_rb._fields()], [s_idx, t_idx], self.S, self.A)[0]
+            tr, _ = self.rollout(init, cfg["rollout_from_src_length"], use_trg=False)
+            if tr is not None and tr["obss"].shape[0] > 0:
+                self._dara_delta(tr["obss"].contiguous(), tr["actions"].contiguous(), tr["next_obss"].contiguous(),
+                                 tr["rewards"], cfg["penalty_coef"])
+                self.fake_replay_buffer.add_batch(tr)
 
     # ------------------------------------------------------------------ training
     # ------------------------------------------------------------------ HIP-graph fast path
@@ -295,8 +388,8 @@ class MOBODY(object):
             return self._graph_step(src_replay_buffer, tar_replay_buffer, batch_size)
         if self._graph is not None:                       # an eager step (refresh/logging) moves the host-side counts
             self._graph = None
-        if self.penalty_type == "dara":
-            raise NotImplementedError("penalty_type='dara' (classifier warm-up, mobody.py:354-381) is not accelerated yet")
+        if self.penalty_type == "dara" and self.total_it == 1:
+            self._dara_warmup(src_replay_buffer, tar_replay_buffer, batch_size, writer)
         if cfg["advantage"]:
             raise NotImplementedError("advantage=1 (V-function variant) is not accelerated yet")
         S, A = self.S, self.A

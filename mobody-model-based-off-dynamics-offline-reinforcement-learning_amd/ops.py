@@ -230,3 +230,49 @@ def gather_batch_rng(buffers, counts, seeds, call_offsets, counter, sizes, S, A,
     check(load().mobody_gather_batch_rng(views, cnt, n, S, A, sd, off, ptr(counter), sz, *[ptr(t) for t in out],
                                          cur_stream()), "mobody_gather_batch_rng")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# generic MLP gradient + DARA classifier pieces
+# ------------------------------------------------------------------------------------------------
+def mlp3_backward(blob_T, in_dim, out_dim, members, dz3, x, h1, h2, grad, ws=None):
+    rows = x.shape[0]
+    need = load().mobody_mlp3_backward_workspace(in_dim, out_dim, members, rows)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=x.device)
+    check(load().mobody_mlp3_backward(ptr(blob_T), in_dim, out_dim, members, ptr(dz3), ptr(x), ptr(h1), ptr(h2), rows,
+                                      ptr(grad), ptr(ws), cur_stream()), "mobody_mlp3_backward")
+    return ws
+
+
+def dara_inputs(s, a, s2, std, noise_sas=None, noise_sa=None, seed=0, call=0):
+    N, S = s.shape
+    A = a.shape[1]
+    x_sas = torch.empty(N, 2 * S + A, dtype=torch.float32, device=s.device)
+    x_sa = torch.empty(N, S + A, dtype=torch.float32, device=s.device)
+    check(load().mobody_dara_inputs(ptr(s), ptr(a), ptr(s2), N, S, A, float(std), ptr(noise_sas), ptr(noise_sa), seed,
+                                    call, ptr(x_sas), ptr(x_sa), cur_stream()), "mobody_dara_inputs")
+    return x_sas, x_sa
+
+
+def dara_loss_grad(z_sas, z_sa, n_src, labels=None):
+    """z_*: logits [N,2].  Returns (dz_sas[N,16], dz_sa[N,16], loss[2] = (loss_sa, loss_sas))."""
+    N = z_sas.shape[0]
+    dev = z_sas.device
+    dz_sas = torch.empty(N, 16, dtype=torch.float32, device=dev)
+    dz_sa = torch.empty(N, 16, dtype=torch.float32, device=dev)
+    loss = torch.empty(2, dtype=torch.float32, device=dev)
+    lossp = torch.empty(2 * ((N + 255) // 256), dtype=torch.float32, device=dev)
+    if labels is not None:
+        labels = torch.as_tensor(labels).to(device=dev, dtype=torch.int32).contiguous()
+    check(load().mobody_dara_loss_grad(ptr(z_sas), ptr(z_sa), ptr(labels), N, int(n_src), ptr(dz_sas), ptr(dz_sa),
+                                       ptr(loss), ptr(lossp), cur_stream()), "mobody_dara_loss_grad")
+    return dz_sas, dz_sa, loss
+
+
+def dara_penalty(z_sas, z_sa, coef, reward=None, want_delta=False):
+    n = z_sas.shape[0]
+    delta = torch.empty(n, 1, dtype=torch.float32, device=z_sas.device) if want_delta or reward is None else None
+    check(load().mobody_dara_penalty(ptr(z_sas), ptr(z_sa), n, float(coef), ptr(reward), ptr(delta), cur_stream()),
+          "mobody_dara_penalty")
+    return delta

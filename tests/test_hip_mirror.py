@@ -267,3 +267,75 @@ def test_graph_replay_matches_eager_steps(dev):
     close(g.q_funcs.blob, e.q_funcs.blob, rtol=1e-6, atol=1e-8)
     close(g.policy.blob, e.policy.blob, rtol=1e-6, atol=1e-8)
     close(g.target_q_funcs.blob, e.target_q_funcs.blob, rtol=1e-6, atol=1e-8)
+
+
+def test_dara_classifier_vs_reference_golden(dev):
+    """G9: classifier probabilities, the log-ratio penalty and one update_classifier step (loss + gradients)
+    with the reference's recorded permutation and input noise."""
+    from mobody_amd import ops
+    from mobody_amd.algo.offline_offline.mobody import MOBODY
+    g = gu.load("g9_dara")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    cfg = gu.policy_cfg(S, A, penalty_type="dara")
+    pol = MOBODY(cfg, dev)
+    pc = {}
+    pc.update({"sa_classifier." + k: v for k, v in gu.gi.mlp_params(int(g["seed_sa"]), S + A, 2).items()})
+    pc.update({"sas_classifier." + k: v for k, v in gu.gi.mlp_params(int(g["seed_sas"]), 2 * S + A, 2).items()})
+    pol.classifier.load_state_dict({k: torch.from_numpy(v) for k, v in pc.items()})
+    assert sorted(pol.classifier.state_dict()) == sorted(pc)
+    td = lambda x: torch.from_numpy(x).to(dev).contiguous()
+    ps, pa = pol.classifier(td(g["s"]), td(g["a"]), td(g["s2"]), with_noise=False)
+    close(ps, g["probs_sas"]); close(pa, g["probs_sa"])
+    close(pol._dara_delta(td(g["s"]), td(g["a"]), td(g["s2"])), g["delta_r"], rtol=1e-4, atol=2e-5)
+    rew = torch.zeros(64, 1, device=dev)
+    pol._dara_delta(td(g["s"]), td(g["a"]), td(g["s2"]), rew, 0.1)
+    close(rew, 0.1 * g["delta_r"], rtol=1e-4, atol=2e-6)
+    # one update with the reference's permuted rows / labels / noise
+    src = gu.gi.batch(704, 64, S, A); tar = gu.gi.batch(705, 64, S, A)
+    perm = g["perm"]
+    rows = tuple(td(np.concatenate([src[i][:bs], tar[i][:bs]], 0)[perm]) for i in range(3))
+    labels = np.concatenate([np.zeros(bs), np.ones(bs)])[perm]
+    loss_sa, loss_sas = pol.update_classifier(None, None, bs, rows=rows, labels=labels,
+                                              noise=(td(g["noise_sas"]), td(g["noise_sa"])))
+    close(float(loss_sa), float(g["loss_sa"]), rtol=1e-5, atol=0)
+    close(float(loss_sas), float(g["loss_sas"]), rtol=1e-5, atol=0)
+    grads = {}
+    for net, opt in ((pol.classifier.sa_classifier, pol.classifier.opt_sa), (pol.classifier.sas_classifier, pol.classifier.opt_sas)):
+        from mobody_amd import packing
+        gm = packing.unpack_mlp(opt.grad, net.in_dim, 2, 1)[0]
+        grads.update({net.prefixes[0] + k: v for k, v in gm.items()})
+    scale = max(float(np.abs(g[k]).max()) for k in g if k.startswith("cls_g::"))
+    for k, v in grads.items():
+        close(gu.sub(v.cpu().numpy()), g["cls_g::" + k], rtol=1e-5, atol=1e-5 * scale)
+    for k, v in pol.classifier.state_dict().items():
+        from test_hip_train import params_close
+        # saturated softmax heads leave many gradients at the 1e-9 rounding floor, where Adam's sign-like first
+        # step can differ by a sizeable fraction of lr between two fp32 summation orders
+        params_close(gu.sub(v.cpu().numpy()), g["cls_p::" + k], cfg["actor_lr"], max_frac=0.5)
+
+
+def test_dara_penalty_type_end_to_end(dev):
+    """penalty_type='dara': the first train() call trains the classifier (cut to a few steps here) and rewrites the
+    source rewards once; later calls leave them alone."""
+    from mobody_amd import synthetic
+    from mobody_amd.algo import utils
+    from mobody_amd.algo.call_algo import call_algo
+    from mobody_amd.algo.offline_offline import mobody as mod
+    S, A, task = 45, 24, "pen-human-v1"
+    cfg = gu.policy_cfg(S, A, rng="device", penalty_type="dara", src_rollout_length=0, trg_rollout_length=0,
+                        use_src_sa_to_get_target_next_state=0, fake_batch_scale=0)
+    pol = call_algo("mobody", cfg, 3, dev)
+    src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=3000, rng="device", seed=1), 3000, task, 0)
+    tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=500, rng="device", seed=2), 500, task, 1)
+    r0 = src.reward.clone()
+    calls = []
+    orig = pol.update_classifier
+    pol.update_classifier = lambda *a, **k: (calls.append(1), orig(*a, **k))[1] if len(calls) < 8 else calls.append(1)
+    pol.train(src, tar, 64, None, None)
+    assert len(calls) == 5000                                  # 10*500 iterations at total_it == 1 (mobody.py:356)
+    d = (src.reward - r0).abs()
+    assert float(d.max()) > 0 and float(d.max()) <= 0.1 * 10 + 1e-6        # |penalty_coef * clamp(.,-10,10)|
+    r1 = src.reward.clone()
+    pol.train(src, tar, 64, None, None)
+    assert torch.equal(src.reward, r1) and len(calls) == 5000
+    assert all(np.isfinite(x) for x in pol.losses())

@@ -29,13 +29,13 @@ def close(a, b, rtol=1e-5, atol=1e-5):
     np.testing.assert_allclose(a.astype(np.float64), b.astype(np.float64), rtol=rtol, atol=atol)
 
 
-def params_close(a, b, lr):
+def params_close(a, b, lr, max_frac=0.1):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
     d = np.abs(a.astype(np.float64) - b.astype(np.float64))
     tight = d <= 1e-6 + 1e-5 * np.abs(b)
     assert tight.mean() >= 0.995, f"only {tight.mean():.4f} of the entries within 1e-5"
-    assert d.max() <= 0.1 * lr, f"max deviation {d.max():.3e} exceeds 0.1*lr"
+    assert d.max() <= max_frac * lr, f"max deviation {d.max():.3e} exceeds {max_frac}*lr"
 
 
 @pytest.fixture(scope="module")
