@@ -200,8 +200,11 @@ int64_t mobody_train_workspace(const MobodyTrainDims* d);
  * the LOCAL rows scaled by 1/N_global (sum over ranks == global loss). */
 int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* q_blob,
                        const float* q_blob_T, const float* qtarg_blob, const float* state, const float* action,
-                       const float* next_state, const float* reward, const float* not_done, float* grad_q,
-                       float* loss_out, float* workspace, void* stream);
+                       const float* next_state, const float* reward, const float* not_done, const float* q_next,
+                       float* grad_q, float* loss_out, float* workspace, void* stream);
+/* q_next: NULL -> min target-Q(s', pi(s')) is computed here (update_q_functions, mobody.py:189-208); non-NULL ->
+ * [N] bootstrap values supplied by the caller, V(s') in the advantage variant (update_q_functions_1, :210-229;
+ * actor_blob / qtarg_blob / next_state may then be NULL). */
 
 /* Actor phase, part 1: forwards + the two batch statistics stats[0]=sum|min Q(s,pi(s))|,
  * stats[1]=sum|min Q(s_t,a_t)| over LOCAL rows (all-reduce them across ranks before part 2). */
@@ -211,8 +214,14 @@ int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const f
 /* Actor phase, part 2: grad_actor (MobodyMlpLayout(S,A,1)) and loss_out[0]=L_pi, [1]=L_BC (local share). */
 int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
                           const float* actor_blob_T, const float* q_blob, const float* q_blob_T, const float* state,
-                          const float* action, const float* stats, float* grad_actor, float* loss_out,
-                          float* workspace, void* stream);
+                          const float* action, const float* stats, const float* v_true, float* grad_actor,
+                          float* loss_out, float* workspace, void* stream);
+/* v_true: NULL -> BC weights exp(3*q_b/mean|q_b|); [Nt] V(s_true) -> exp(3*(q_b - V)) (config['advantage'], :255-256). */
+
+/* Expectile loss of the V function (update_v_function, mobody.py:231-242): adv = min(qt[0],qt[1]) - v;
+ * dz3[N][16] column 0 = dL_V/dV (1/N_global scaling), loss_out[0] = local share of L_V; lossp_ws: ceil(N/256) floats. */
+int mobody_value_loss_grad(const float* qt, const float* v, int64_t N, int64_t N_global, float* dz3, float* loss_out,
+                           float* lossp_ws, void* stream);
 
 /* Adam (torch defaults b1=.9 b2=.999 eps=1e-8) on a packed blob, 1-based step t; optional Polyak
  * target update target = tau*p + (1-tau)*target (tau < 0 or target == NULL: skip); refreshes the

@@ -12,7 +12,8 @@ per-rank minibatch is `batch_size` rows per buffer, gradients are all-reduced (R
 blobs per step and the two batch statistics of the actor loss as one 2-float message, so the
 N-GPU update equals the 1-GPU update on the concatenated batch.
 
-Not implemented on this path yet (raises NotImplementedError): `advantage=1` (V-function variant).
+All MOBODY variants of the reference path are covered: penalty_type none/par/dara, scale_Q, q_weighted,
+advantage (V-function), fake_batch_scale=0, rollout_from_src.
 """
 import numpy as np
 import torch
@@ -181,6 +182,9 @@ class MOBODY(object):
         self.q_funcs = _PackedNet(S + A, 1, 2, ("network1.", "network2."), self.device)
         self.target_q_funcs = self.q_funcs.clone().eval()                         # deepcopy, mobody.py:116
         self.policy = _PackedNet(S, A, 1, ("network.",), self.device, out_mode=1, max_action=config["max_action"])
+        self.v_func = _PackedNet(S, 1, 1, ("network.",), self.device)                # ValueFunc, mobody.py:50-57,121
+        self.v_optimizer = _Adam(self.v_func, config["critic_lr"])
+        self._v_ws = None
         self.q_optimizer = _Adam(self.q_funcs, config["critic_lr"])
         self.policy_optimizer = _Adam(self.policy, config["actor_lr"])
         self.classifier = _Classifier(S, A, self.device, config["gaussian_noise_std"], config["actor_lr"])
@@ -390,8 +394,6 @@ class MOBODY(object):
             self._graph = None
         if self.penalty_type == "dara" and self.total_it == 1:
             self._dara_warmup(src_replay_buffer, tar_replay_buffer, batch_size, writer)
-        if cfg["advantage"]:
-            raise NotImplementedError("advantage=1 (V-function variant) is not accelerated yet")
         S, A = self.S, self.A
         ns, nt = int(cfg["src_ratio"] * batch_size), int(cfg["trg_ratio"] * batch_size)
         nf = int(cfg["fake_batch_scale"] * batch_size) if cfg["fake_batch_scale"] != 0 else 0
@@ -450,10 +452,31 @@ class MOBODY(object):
             self._ws_key = (N, Nt)
         return ops.train_dims(self.S, self.A, N, Nt, Ng, Ntg), ops.hyper(self.config)
 
+    # V-function phase of the advantage variant (update_v_function, mobody.py:231-242, 533-537)
+    def has_value_phase(self):
+        return bool(self.config["advantage"])
+
+    def value_grad(self, b, N, Nt, Ng, Ntg):
+        S, A = self.S, self.A
+        qt = ops.mlp3_forward(self.target_q_funcs.blob, S + A, 1, 2, b[0], b[1])               # no grad, :233-234
+        v, x, h1, h2 = ops.mlp3_forward(self.v_func.blob, S, 1, 1, b[0], save=True)
+        dz3, loss = ops.value_loss_grad(qt.view(2, N), v.view(N), Ng)
+        self._v_ws = ops.mlp3_backward(self.v_func.blob_T, S, 1, 1, dz3, x, h1, h2, self.v_optimizer.grad, self._v_ws)
+        self._loss[3:4].copy_(loss)
+
+    def value_grad_buffer(self):
+        return self.v_optimizer.grad
+
+    def value_apply(self):
+        self.v_optimizer.step()
+
     def critic_grad(self, b, N, Nt, Ng, Ntg):
         dims, hyp = self._dims(N, Nt, Ng, Ntg)
+        q_next = None
+        if self.config["advantage"]:                                        # update_q_functions_1: y = r + nd*gamma*V(s')
+            q_next = ops.mlp3_forward(self.v_func.blob, self.S, 1, 1, b[2]).view(N)
         ops.critic_step(dims, hyp, self.policy.blob, self.q_funcs.blob, self.q_funcs.blob_T, self.target_q_funcs.blob,
-                        b, self.q_optimizer.grad, self._loss[0:1], self._ws)
+                        b, self.q_optimizer.grad, self._loss[0:1], self._ws, q_next=q_next)
 
     def critic_grad_buffer(self):
         return self.q_optimizer.grad
@@ -470,8 +493,11 @@ class MOBODY(object):
 
     def actor_grad(self, b, N, Nt, Ng, Ntg):
         dims, hyp = self._dims(N, Nt, Ng, Ntg)
+        v_true = None
+        if self.config["advantage"] and Nt > 0:                              # adv = q_b - V(s_true), :254-256
+            v_true = ops.mlp3_forward(self.v_func.blob, self.S, 1, 1, b[0][:Nt]).view(Nt)
         ops.actor_backward(dims, hyp, self.policy.blob, self.policy.blob_T, self.q_funcs.blob, self.q_funcs.blob_T,
-                           b[0], b[1], self._stats, self.policy_optimizer.grad, self._loss[1:3], self._ws)
+                           b[0], b[1], self._stats, self.policy_optimizer.grad, self._loss[1:3], self._ws, v_true=v_true)
 
     def actor_grad_buffer(self):
         return self.policy_optimizer.grad

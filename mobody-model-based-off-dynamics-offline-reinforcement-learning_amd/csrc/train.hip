@@ -84,11 +84,13 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {      // blockDi
 }
 
 // y = r + nd*gamma*min(Qt1,Qt2)(s',pi(s'));  dz3[m] = dL/dq_m = 2 (q_m - y) / N_global   (mobody.py:190-207)
-__global__ __launch_bounds__(256) void k_td_prep(const float* qt, const float* q, const float* r, const float* nd,
-                                                 long long N, float gamma, float invNg, int Np3, float* dz3) {
+__global__ __launch_bounds__(256) void k_td_prep(const float* qt, const float* qnext, const float* q, const float* r,
+                                                 const float* nd, long long N, float gamma, float invNg, int Np3,
+                                                 float* dz3) {
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= N) return;
-  const float y = r[row] + nd[row] * gamma * fminf(qt[row], qt[N + row]);
+  const float qn = qnext ? qnext[row] : fminf(qt[row], qt[N + row]);     // V(s') in the advantage variant (:215)
+  const float y = r[row] + nd[row] * gamma * qn;
   for (int m = 0; m < 2; ++m) {
     float* o = dz3 + (m * N + row) * Np3;
     o[0] = 2.f * (q[m * N + row] - y) * invNg;
@@ -96,12 +98,13 @@ __global__ __launch_bounds__(256) void k_td_prep(const float* qt, const float* q
   }
 }
 
-__global__ __launch_bounds__(1024) void k_td_loss(const float* qt, const float* q, const float* r, const float* nd,
-                                                  long long N, float gamma, float invNg, float* out) {
+__global__ __launch_bounds__(1024) void k_td_loss(const float* qt, const float* qnext, const float* q, const float* r,
+                                                  const float* nd, long long N, float gamma, float invNg, float* out) {
   __shared__ float sm[16];
   float s = 0.f;
   for (long long row = threadIdx.x; row < N; row += blockDim.x) {
-    const float y = r[row] + nd[row] * gamma * fminf(qt[row], qt[N + row]);
+    const float qn = qnext ? qnext[row] : fminf(qt[row], qt[N + row]);
+    const float y = r[row] + nd[row] * gamma * qn;
     const float d0 = q[row] - y, d1 = q[N + row] - y;
     s += d0 * d0 + d1 * d1;
   }
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(1024) void k_actor_stats(const float* qp, const flo
 
 struct ActorRowArgs {
   const float *qp, *qb, *stats, *pi, *act, *dxa;
+  const float* v_true;       // [Nt] V(s_true) when config['advantage'] (else null)
   float *dz3q, *bcw, *dz3a, *loss_out, *lossp;
   long long N, Nt, Ng, Ntg;
   int A, Np3q, Np3a;
@@ -135,7 +139,8 @@ __device__ __forceinline__ float policy_weight(const ActorRowArgs& a) {       //
 __device__ __forceinline__ float bc_weight(const ActorRowArgs& a, long long row) {   // exp_adv, :257-267
   if (!a.h.q_weighted) return 1.f;
   const float qb = fminf(a.qb[row], a.qb[a.Nt + row]);
-  const float adv = qb / (a.stats[1] / (float)a.Ntg);
+  const float adv = a.v_true ? qb - a.v_true[row]                      // advantage variant, mobody.py:255-256
+                             : qb / (a.stats[1] / (float)a.Ntg);
   return fminf(expf(3.f * adv), 100.f);
 }
 
@@ -196,6 +201,32 @@ __global__ __launch_bounds__(256) void k_actor_loss(ActorRowArgs a, int nparts) 
     a.loss_out[0] = policy_weight(a) * s0 / (float)a.Ng + a.h.bc_coef * bc;
     a.loss_out[1] = bc;
   }
+}
+
+// expectile regression of V towards min target-Q (update_v_function, mobody.py:231-242; asymmetric_l2_loss :85-86):
+// adv = min(Qt1,Qt2)(s,a) - V(s); L_V = mean(|0.7 - 1[adv<0]| * adv^2); dz3[row][0] = dL/dV
+__global__ __launch_bounds__(256) void k_v_loss(const float* qt, const float* v, long long N, float invNg, int Np3,
+                                                float* dz3, float* lossp) {
+  __shared__ float sm[4];
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  float l = 0.f;
+  if (row < N) {
+    const float adv = fminf(qt[row], qt[N + row]) - v[row];
+    const float w = fabsf(0.7f - (adv < 0.f ? 1.f : 0.f));
+    l = w * adv * adv;
+    float* o = dz3 + row * Np3;
+    o[0] = -2.f * w * adv * invNg;
+    for (int c = 1; c < Np3; ++c) o[c] = 0.f;
+  }
+  l = block_sum(l, sm);
+  if (threadIdx.x == 0) lossp[blockIdx.x] = l;
+}
+__global__ __launch_bounds__(256) void k_sum_scale(const float* parts, int n, float scale, float* out) {
+  __shared__ float sm[4];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < n; k += blockDim.x) s += parts[k];
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) out[0] = s * scale;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -336,31 +367,34 @@ extern "C" int64_t mobody_train_workspace(const MobodyTrainDims* d) {
 extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
                                   const float* q_blob, const float* q_blob_T, const float* qtarg_blob,
                                   const float* state, const float* action, const float* next_state,
-                                  const float* reward, const float* not_done, float* grad_q, float* loss_out,
-                                  float* workspace, void* stream) {
+                                  const float* reward, const float* not_done, const float* q_next, float* grad_q,
+                                  float* loss_out, float* workspace, void* stream) {
   int rc = check_dims(d, "mobody_critic_step");
   if (rc) return rc;
-  MB_REQUIRE(h && actor_blob && q_blob && q_blob_T && qtarg_blob && state && action && next_state && reward && not_done &&
-                 grad_q && loss_out && workspace, "mobody_critic_step: null pointer");
+  MB_REQUIRE(h && q_blob && q_blob_T && state && action && reward && not_done && grad_q && loss_out && workspace,
+             "mobody_critic_step: null pointer");
+  MB_REQUIRE(q_next || (actor_blob && qtarg_blob && next_state), "mobody_critic_step: need q_next or actor/target/next_state");
   TrainWs w;
   rc = carve(*d, workspace, w);
   if (rc) return rc;
   hipStream_t st = as_stream(stream);
   const long long N = d->N;
   const int S = d->S, A = d->A;
-  // a' = pi(s')                                                             (mobody.py:191)
-  rc = launch_mlp3_fwd(fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pi, 1, h->max_action, nullptr, nullptr, nullptr), 1, ACT_RELU, st);
-  if (rc) return rc;
-  // target twin-Q(s', a')                                                    (:192)
-  rc = launch_mlp3_fwd(fwd_args(qtarg_blob, w.Lq, next_state, S, w.pi, A, N, w.qt, 0, 1.f, nullptr, nullptr, nullptr), 2, ACT_RELU, st);
-  if (rc) return rc;
+  if (q_next == nullptr) {
+    // a' = pi(s')                                                             (mobody.py:191)
+    rc = launch_mlp3_fwd(fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pi, 1, h->max_action, nullptr, nullptr, nullptr), 1, ACT_RELU, st);
+    if (rc) return rc;
+    // target twin-Q(s', a')                                                    (:192)
+    rc = launch_mlp3_fwd(fwd_args(qtarg_blob, w.Lq, next_state, S, w.pi, A, N, w.qt, 0, 1.f, nullptr, nullptr, nullptr), 2, ACT_RELU, st);
+    if (rc) return rc;
+  }   // else: q_next = V(s') supplied by the caller (update_q_functions_1, :210-229)
   // online twin-Q(s, a), activations kept for the backward                   (:196)
   rc = launch_mlp3_fwd(fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q), 2, ACT_RELU, st);
   if (rc) return rc;
   const float invNg = 1.f / (float)d->N_global;
-  hipLaunchKernelGGL(k_td_prep, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, w.qt, w.q, reward, not_done, N, h->gamma, invNg, w.Lq.Np3, w.dz3q);
+  hipLaunchKernelGGL(k_td_prep, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, w.qt, q_next, w.q, reward, not_done, N, h->gamma, invNg, w.Lq.Np3, w.dz3q);
   MB_LAUNCH_OK("k_td_prep");
-  hipLaunchKernelGGL(k_td_loss, dim3(1), dim3(1024), 0, st, w.qt, w.q, reward, not_done, N, h->gamma, invNg, loss_out);
+  hipLaunchKernelGGL(k_td_loss, dim3(1), dim3(1024), 0, st, w.qt, q_next, w.q, reward, not_done, N, h->gamma, invNg, loss_out);
   MB_LAUNCH_OK("k_td_loss");
   rc = launch_mlp3_bwd(bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp), 2, false, w.tile_rows, st);
   if (rc) return rc;
@@ -395,8 +429,8 @@ extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper*
 
 extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
                                      const float* actor_blob_T, const float* q_blob, const float* q_blob_T,
-                                     const float* state, const float* action, const float* stats, float* grad_actor,
-                                     float* loss_out, float* workspace, void* stream) {
+                                     const float* state, const float* action, const float* stats, const float* v_true,
+                                     float* grad_actor, float* loss_out, float* workspace, void* stream) {
   int rc = check_dims(d, "mobody_actor_backward");
   if (rc) return rc;
   MB_REQUIRE(h && actor_blob && actor_blob_T && q_blob && q_blob_T && state && action && stats && grad_actor && loss_out &&
@@ -407,7 +441,7 @@ extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper
   hipStream_t st = as_stream(stream);
   const long long N = d->N;
   ActorRowArgs ra{};
-  ra.qp = w.q; ra.qb = w.qb; ra.stats = stats; ra.pi = w.pi; ra.act = action; ra.dxa = w.dxa;
+  ra.qp = w.q; ra.qb = w.qb; ra.stats = stats; ra.pi = w.pi; ra.act = action; ra.dxa = w.dxa; ra.v_true = v_true;
   ra.dz3q = w.dz3q; ra.bcw = w.bcw; ra.dz3a = w.dz3a; ra.loss_out = loss_out; ra.lossp = w.lossp;
   ra.N = N; ra.Nt = d->Nt; ra.Ng = d->N_global; ra.Ntg = d->Nt_global > 0 ? d->Nt_global : 1;
   ra.A = d->A; ra.Np3q = w.Lq.Np3; ra.Np3a = w.La.Np3; ra.h = *h;
@@ -494,5 +528,21 @@ extern "C" int mobody_par_penalty(const float* next_state_true, const float* nex
   hipLaunchKernelGGL(k_par_penalty, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), next_state_true,
                      next_state_model, reward, coef, (long long)n, S);
   MB_LAUNCH_OK("k_par_penalty");
+  return 0;
+}
+
+
+// ---- V-function expectile loss (advantage variant): dz3[N][16] and loss_out[0] = local share of L_V ----
+extern "C" int mobody_value_loss_grad(const float* qt, const float* v, int64_t N, int64_t N_global, float* dz3,
+                                      float* loss_out, float* lossp_ws, void* stream) {
+  MB_REQUIRE(N >= 1 && N_global >= N, "mobody_value_loss_grad: bad sizes");
+  MB_REQUIRE(qt && v && dz3 && loss_out && lossp_ws, "mobody_value_loss_grad: null pointer");
+  const int nb = (int)cdiv(N, 256);
+  const float invNg = 1.f / (float)N_global;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_v_loss, dim3(nb), dim3(256), 0, st, qt, v, (long long)N, invNg, 16, dz3, lossp_ws);
+  MB_LAUNCH_OK("k_v_loss");
+  hipLaunchKernelGGL(k_sum_scale, dim3(1), dim3(256), 0, st, lossp_ws, nb, invNg, loss_out);
+  MB_LAUNCH_OK("k_sum_scale");
   return 0;
 }

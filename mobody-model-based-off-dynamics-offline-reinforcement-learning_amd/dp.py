@@ -29,6 +29,11 @@ def dp_update(engine, batch, n_rows, n_true, dist=None, equal_shards=True):
         cnt = torch.tensor([n_rows, n_true], dtype=torch.int64, device=engine.comm_device())
         dist.all_reduce(cnt)
         n_glob, nt_glob = int(cnt[0]), int(cnt[1])
+    if getattr(engine, "has_value_phase", lambda: False)():      # config['advantage']: V update first (mobody.py:533-537)
+        engine.value_grad(batch, n_rows, n_true, n_glob, nt_glob)
+        if world > 1:
+            dist.all_reduce(engine.value_grad_buffer())
+        engine.value_apply()
     engine.critic_grad(batch, n_rows, n_true, n_glob, nt_glob)
     if world > 1:
         dist.all_reduce(engine.critic_grad_buffer())

@@ -120,10 +120,10 @@ def mlp_transpose(blob, in_dim, out_dim, members):
     return bt
 
 
-def critic_step(dims, hyp, actor_blob, q_blob, q_blob_T, qtarg_blob, batch, grad_q, loss_out, ws):
+def critic_step(dims, hyp, actor_blob, q_blob, q_blob_T, qtarg_blob, batch, grad_q, loss_out, ws, q_next=None):
     s, a, s2, r, nd = batch
     check(load().mobody_critic_step(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(q_blob), ptr(q_blob_T),
-                                    ptr(qtarg_blob), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(grad_q),
+                                    ptr(qtarg_blob), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(q_next), ptr(grad_q),
                                     ptr(loss_out), ptr(ws), cur_stream()), "mobody_critic_step")
 
 
@@ -133,10 +133,21 @@ def actor_forward(dims, hyp, actor_blob, q_blob, state, action, stats, ws):
 
 
 def actor_backward(dims, hyp, actor_blob, actor_blob_T, q_blob, q_blob_T, state, action, stats, grad_actor, loss_out,
-                   ws):
+                   ws, v_true=None):
     check(load().mobody_actor_backward(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(actor_blob_T), ptr(q_blob),
-                                       ptr(q_blob_T), ptr(state), ptr(action), ptr(stats), ptr(grad_actor),
+                                       ptr(q_blob_T), ptr(state), ptr(action), ptr(stats), ptr(v_true), ptr(grad_actor),
                                        ptr(loss_out), ptr(ws), cur_stream()), "mobody_actor_backward")
+
+
+def value_loss_grad(qt, v, n_global):
+    """qt [2,N] target twin-Q(s,a), v [N] -> (dz3[N,16], loss[1]) of the expectile V loss."""
+    N = v.numel()
+    dz3 = torch.empty(N, 16, dtype=torch.float32, device=v.device)
+    loss = torch.empty(1, dtype=torch.float32, device=v.device)
+    lossp = torch.empty((N + 255) // 256, dtype=torch.float32, device=v.device)
+    check(load().mobody_value_loss_grad(ptr(qt), ptr(v), N, int(n_global), ptr(dz3), ptr(loss), ptr(lossp), cur_stream()),
+          "mobody_value_loss_grad")
+    return dz3, loss
 
 
 def adam_polyak(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t, lr, tau=-1.0, grad_scale=1.0):

@@ -107,7 +107,7 @@ class FixedRows:
         self.calls = []
 
 
-@pytest.mark.parametrize("tag", ["default", "noqw", "noscale", "nofake", "bc05", "par"])
+@pytest.mark.parametrize("tag", ["default", "noqw", "noscale", "nofake", "bc05", "par", "adv"])
 def test_mirror_train_vs_reference_golden(tag, dev):
     from mobody_amd.algo.offline_offline.mobody import MOBODY
     from test_hip_train import params_close
@@ -115,10 +115,11 @@ def test_mirror_train_vs_reference_golden(tag, dev):
     S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
     cfg = gu.policy_cfg(S, A, **gu.G7_VARIANTS[tag])
     pol = MOBODY(cfg, dev)
-    pa, pq, _ = gu.policy_params(int(g["seed"]), S, A)
+    pa, pq, pv = gu.policy_params(int(g["seed"]), S, A)
     pol.policy.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
     pol.q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
     pol.target_q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+    pol.v_func.load_state_dict({k: torch.from_numpy(v) for k, v in pv.items()})
     src = FixedRows(gu.gi.batch(501, 64, S, A), S, A, dev).rb
     tar = FixedRows(gu.gi.batch(502, 64, S, A), S, A, dev).rb
     pol.fake_replay_buffer = FixedRows(gu.gi.batch(503, 64, S, A), S, A, dev).rb
@@ -134,7 +135,7 @@ def test_mirror_train_vs_reference_golden(tag, dev):
         close(q_loss, g["q_loss"][step - 1], rtol=1e-5, atol=0)
         close(pi_loss, g["pi_loss"][step - 1], rtol=5e-5, atol=2e-5)
         close(bc_loss, g["bc_loss"][step - 1], rtol=5e-5, atol=2e-5)
-        for nm, net in (("q", pol.q_funcs), ("actor", pol.policy), ("qt", pol.target_q_funcs)):
+        for nm, net in (("q", pol.q_funcs), ("actor", pol.policy), ("qt", pol.target_q_funcs), ("v", pol.v_func)):
             for k, v in net.state_dict().items():
                 params_close(gu.sub(v.cpu().numpy()), g[f"s{step}_{nm}_p::{k}"], cfg["critic_lr"])
     assert pol.total_it == 3
