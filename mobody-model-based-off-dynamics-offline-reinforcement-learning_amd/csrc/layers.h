@@ -19,7 +19,7 @@ __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ 
   wide_gemm<MT>(Xs, W, Kp, acc);
   lds_barrier();                         // every wave has finished reading the old image
   // the wave's two bias values (columns 64w + 32nt + lane&31) are fetched once, not per accumulator element
-  const float bias0 = b[64 * wave_id() + (lane_id() & 31)], bias1 = b[64 * wave_id() + 32 + (lane_id() & 31)];
+  const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
   wide_foreach<MT>(acc, [&](int row, int col, float v) {
     const float y = activate<ACT>(v + ((col & 32) ? bias1 : bias0));
     Xs[row * LDX + col] = y;

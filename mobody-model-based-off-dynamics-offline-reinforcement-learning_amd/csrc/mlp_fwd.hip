@@ -10,10 +10,10 @@
 
 namespace mobody {
 
-template <int ACT, int MT>
-__global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_fwd(Mlp3FwdArgs a) {
+template <int ACT, int MT, int RG>
+__global__ __launch_bounds__(NTHREADS * RG, 2) void k_mlp3_fwd(Mlp3FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
-  constexpr int TB = 32 * MT;                     // rows of this workgroup's tile
+  constexpr int TB = 32 * MT * RG;                // rows of this workgroup's tile
   const int m = blockIdx.y;
   const long long row0 = (long long)blockIdx.x * TB;
   const int rows_here = (int)min((long long)TB, a.rows - row0);
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_fwd(Mlp3FwdArgs a) {
   tile_zero_cols(Xs, c0, a.Kp1, TB);
   lds_barrier();
   if (a.save_x != nullptr && m == 0) {
-    for (int idx = threadIdx.x; idx < rows_here * a.Kp1; idx += NTHREADS) {
+    for (int idx = threadIdx.x; idx < rows_here * a.Kp1; idx += NTHREADS * RG) {
       const int r = idx / a.Kp1, c = idx - r * a.Kp1;
       a.save_x[(row0 + r) * a.Kp1 + c] = Xs[r * LDX + c];
     }
@@ -57,28 +57,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_fwd(Mlp3FwdArgs a) {
   }, TB);
 }
 
-template <int ACT, int MT>
+template <int ACT, int MT, int RG>
 static int launch_fwd_t(const Mlp3FwdArgs& a, int members, hipStream_t stream) {
-  size_t lds = (size_t)32 * MT * LDX * sizeof(float);
+  size_t lds = (size_t)32 * MT * RG * LDX * sizeof(float);
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_mlp3_fwd<ACT, MT>, 160 * 1024);
+    int rc = allow_big_lds(k_mlp3_fwd<ACT, MT, RG>, 160 * 1024);
     if (rc) return rc;
     once = true;
   }
-  if (const char* e = getenv("MOBODY_FWD_LDS_KB")) { size_t v = (size_t)atoi(e) * 1024; if (v > lds) lds = v; }
-  dim3 grid((unsigned)cdiv(a.rows, 32 * MT), (unsigned)members);
+  dim3 grid((unsigned)cdiv(a.rows, 32 * MT * RG), (unsigned)members);
   ProfScope prof(PROF_MLP_FWD, stream);
-  hipLaunchKernelGGL((k_mlp3_fwd<ACT, MT>), grid, dim3(NTHREADS), lds, stream, a);
+  hipLaunchKernelGGL((k_mlp3_fwd<ACT, MT, RG>), grid, dim3(NTHREADS * RG), lds, stream, a);
   MB_LAUNCH_OK("k_mlp3_fwd");
   return 0;
 }
 
 int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stream) {
   if (a.rows <= 0) return 0;
-  const bool small = pick_tile_rows(a.rows, members) == 32;
-  if (act == ACT_SWISH) return small ? launch_fwd_t<ACT_SWISH, 1>(a, members, stream) : launch_fwd_t<ACT_SWISH, 2>(a, members, stream);
-  return small ? launch_fwd_t<ACT_RELU, 1>(a, members, stream) : launch_fwd_t<ACT_RELU, 2>(a, members, stream);
+  static const int shape = [] { const char* e = getenv("MOBODY_FWD_SHAPE"); return e ? atoi(e) : 0; }();   // tuning aid
+  const bool tall = pick_tile_rows(a.rows, members) == 64;
+  if (act == ACT_SWISH) {
+    if (shape == 8) return launch_fwd_t<ACT_SWISH, 1, 2>(a, members, stream);
+    return tall ? launch_fwd_t<ACT_SWISH, 2, 1>(a, members, stream) : launch_fwd_t<ACT_SWISH, 1, 1>(a, members, stream);
+  }
+  if (shape == 8) return launch_fwd_t<ACT_RELU, 1, 2>(a, members, stream);
+  return tall ? launch_fwd_t<ACT_RELU, 2, 1>(a, members, stream) : launch_fwd_t<ACT_RELU, 1, 1>(a, members, stream);
 }
 
 }  // namespace mobody

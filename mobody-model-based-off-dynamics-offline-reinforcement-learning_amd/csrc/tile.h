@@ -37,6 +37,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+// Workgroups have 4*RG waves: wave w owns output columns [64*(w&3), +64) of the row group w>>2 (rows
+// [32*MT*(w>>2), +32*MT) of the tile).  RG = 2 puts two waves on every weight-column slice: their B-fragment
+// requests are identical and merge in the CU's L1, so a 64-row tile streams the weights once instead of twice.
+__device__ __forceinline__ int wave_col() { return (threadIdx.x >> 6) & 3; }
+__device__ __forceinline__ int wave_rg() { return threadIdx.x >> 8; }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits s_waitcnt vmcnt(0), which parks
 // every wave until its outstanding GLOBAL loads/stores (activation saves, prefetched masks) have retired;
@@ -77,19 +82,21 @@ template <int MT>
 __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const float* __restrict__ W, int Kp,
                                           f32x16 (&acc)[MT][2]) {
   constexpr int R = 5;                          // register ring: weight fragments are requested R-1 = 4 chunks ahead
-  const int lane = lane_id(), w = wave_id();
+  const int lane = lane_id(), w = wave_col();
   const int i = lane & 31, h = lane >> 5;
   const int kh = Kp >> 1;                       // K range of this lane half, multiple of 4
   const int nch = kh >> 2;                      // chunks of four k-steps
-  const float* xa = Xs + i * LDX + h * kh;
-  const float* wb = W + ((size_t)(h * nch) * HID + 64 * w + i) * 4;
+  const float* xa = Xs + (32 * MT * wave_rg() + i) * LDX + h * kh;
+  // per-lane part of the weight address as a 32-bit element offset; the chunk advance is wave-uniform, so the loads
+  // can use the scalar-base + vector-offset form instead of 64-bit vector adds in the unrolled loop
+  const int lane_off = ((h * nch) * HID + 64 * w + i) * 4;
   // One chunk is 8*MT MFMAs = 512*MT cycles of this wave's pipe time, while an L2 round trip under load is
   // ~0.9 us (~2000 cycles): throughput per wave = bytes in flight / latency, so 4 chunks (2 KB per wave) are
   // kept in flight.  (With 2 chunks of 4-byte loads the 640-workgroup twin-Q forward ran at 35 % MFMA busy.)
   auto ldb = [&](int c, f32x4 (&b)[2]) {
-    const float* wn = wb + (size_t)c * (HID * 4);
-    b[0] = *reinterpret_cast<const f32x4*>(wn);
-    b[1] = *reinterpret_cast<const f32x4*>(wn + 128);
+    const float* wn = W + (size_t)c * (HID * 4);
+    b[0] = *reinterpret_cast<const f32x4*>(wn + lane_off);
+    b[1] = *reinterpret_cast<const f32x4*>(wn + lane_off + 128);
   };
   auto mma = [&](int c, f32x4 (&b)[2]) {
     f32x4 av[MT];
@@ -113,7 +120,12 @@ __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const fl
       const int c = c0 + j;
       if (c < nch) {
         if (c + R - 1 < nch) ldb(c + R - 1, ring[(j + R - 1) % R]);
+        // Pin the issue order: without this fence hipcc sinks each prefetch load down to its first use (it trades
+        // the ring's registers for occupancy), which collapses the 4-chunk prefetch distance to ~1 chunk and puts
+        // an L2 round trip in front of every chunk's MFMAs (seen in the ISA: load ... vmcnt(1) ... mfma of it).
+        __builtin_amdgcn_sched_barrier(0);
         mma(c, ring[j]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -122,15 +134,16 @@ __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const fl
 // Visit every accumulator element of a wide result: f(row 0..32*MT-1, col 0..255, value).
 template <int MT, class F>
 __device__ __forceinline__ void wide_foreach(f32x16 (&acc)[MT][2], F&& f) {
-  const int lane = lane_id(), w = wave_id();
+  const int lane = lane_id(), w = wave_col();
   const int i = lane & 31, h = lane >> 5;
+  const int rbase = 32 * MT * wave_rg();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;   // C/D map of 32x32 MFMA
+        const int row = rbase + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;   // C/D map of 32x32 MFMA
         const int col = 64 * w + 32 * nt + i;
         f(row, col, acc[mt][nt][r]);
       }
@@ -236,11 +249,12 @@ __device__ __forceinline__ void tile_load(float* Xs, int col0, const float* __re
   // directly by its dependent ds_write costs one HBM round trip per element).  Loads are unconditional from a
   // clamped row (a conditional load would branch and drain vmcnt per element); invalid rows are zeroed by select.
   const int total = bm * n;
-  for (int base = 0; base < total; base += 4 * NTHREADS) {
+  const int nthr = (int)blockDim.x;
+  for (int base = 0; base < total; base += 4 * nthr) {
     float v[4]; int dst[4]; bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int idx = min(base + u * NTHREADS + (int)threadIdx.x, total - 1);
+      const int idx = min(base + u * nthr + (int)threadIdx.x, total - 1);
       const int r = idx / n, c = idx - r * n;
       const int gr = row0 + r;
       v[u] = src[(size_t)min(gr, rows - 1) * ld + c];
@@ -249,13 +263,13 @@ __device__ __forceinline__ void tile_load(float* Xs, int col0, const float* __re
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (base + u * NTHREADS + (int)threadIdx.x < total) Xs[dst[u]] = ok[u] ? v[u] : 0.f;
+      if (base + u * nthr + (int)threadIdx.x < total) Xs[dst[u]] = ok[u] ? v[u] : 0.f;
   }
 }
 __device__ __forceinline__ void tile_zero_cols(float* Xs, int c0, int c1, int bm = BM) {
   const int n = c1 - c0;
   if (n <= 0) return;
-  for (int idx = threadIdx.x; idx < bm * n; idx += NTHREADS) {
+  for (int idx = threadIdx.x; idx < bm * n; idx += (int)blockDim.x) {
     const int r = idx / n, c = idx - r * n;
     Xs[r * LDX + c0 + c] = 0.f;
   }
