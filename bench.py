@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch_size", type=int, default=BS)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--graph", type=int, default=2, help="HIP-graph replay of the steady-state step: 0 never, 1 always, 2 auto (minibatches under 4096 rows); 1 GPU only")
+    ap.add_argument("--graph", type=int, default=1, help="HIP-graph replay of the steady-state step: 0 never, 1 always, 2 auto (minibatches under 4096 rows); 1 GPU only")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -205,6 +205,17 @@ def main():
                         unit="TFLOP/s", traffic=None, avg_launch_ms=avg_ms, launches_per_step=d["launches_per_step"],
                         flops_per_launch=per_launch_flops)
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
+        # HBM bytes of one launch of the dominant kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE passes, committed under profiles/; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))
+            fam = [e for e in pm if dom in e["kernel"] and e["fetch_kb_raw"] and e["write_kb"]]
+            if fam and bs == BS:
+                e = max(fam, key=lambda e: e["launches"])
+                roofline["traffic"] = (2.0 * e["fetch_kb_raw"] + e["write_kb"]) * 1024.0
+                roofline["traffic_note"] = f"PMC avg over {e['launches']} launches of {e['kernel'].strip()} grid {e['grid']}"
+        except Exception:
+            pass
         out = {
             "metric": "transitions/sec", "value": N * world * args.steps / dt, "unit": "transitions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,

@@ -27,8 +27,12 @@
  *     never throws; mobody_last_error() gives the text (thread local);
  *   - not thread safe per stream: one caller per stream.
  *   - network weights are passed as PACKED blobs whose layout is computed by
- *     mobody_dyn_layout / mobody_mlp_layout (zero padded [K_pad][N_pad] per member);
- *     the host-side mirror packs/unpacks the reference's state_dict tensors.
+ *     mobody_dyn_layout / mobody_mlp_layout (zero padded [K_pad][N_pad] per member; matrices with
+ *     N_pad == 256 are stored K-interleaved by four, element (k,n) at ((k/4)*256 + n)*4 + k%4, narrow
+ *     ones row major); the host-side mirror (mobody_amd/packing.py) packs/unpacks the reference's
+ *     state_dict tensors;
+ *   - mobody_critic_step / mobody_actor_forward fork one independent launch onto a library-owned side
+ *     stream and join it back before returning: from the caller's side everything is ordered on `stream`.
  */
 #ifndef MOBODY_HIP_H
 #define MOBODY_HIP_H

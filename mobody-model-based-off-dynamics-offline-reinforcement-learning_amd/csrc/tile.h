@@ -102,6 +102,7 @@ __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const fl
     f32x4 av[MT];
 #pragma unroll
     for (int x = 0; x < MT; ++x) av[x] = *reinterpret_cast<const f32x4*>(xa + 32 * x * LDX + 4 * c);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -109,6 +110,7 @@ __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const fl
         acc[x][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][u], b[0][u], acc[x][0], 0, 0, 0);
         acc[x][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][u], b[1][u], acc[x][1], 0, 0, 0);
       }
+    __builtin_amdgcn_s_setprio(0);
   };
   f32x4 ring[R][2];
 #pragma unroll
