@@ -44,18 +44,6 @@ struct ProfScope {
   ~ProfScope();
 };
 
-// Fork/join helper: independent launches inside one C-ABI call run on a library-owned side stream that is
-// ordered after everything already enqueued on the caller's stream (fork) and joined back before the call
-// returns, so from the caller's side all work is still ordered on `stream` (and is graph-capturable: the side
-// stream joins the capture through the event dependencies).  MOBODY_NO_SIDE_STREAM=1 serialises on the caller's
-// stream (tuning aid).
-struct SideStream {
-  hipStream_t main, side;
-  bool active;
-  explicit SideStream(hipStream_t main_stream);
-  void join();                       // later work on `main` waits for everything launched on side()
-  hipStream_t side_stream() const { return active ? side : main; }
-};
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -40,31 +40,6 @@ ProfScope::~ProfScope() {
   if (slot >= 0) (void)hipEventRecord(prof_pool()[slot].b, st);
 }
 
-// ---- side stream (one per process; created on first use) ----
-static hipStream_t g_side = nullptr;
-static hipEvent_t g_fork = nullptr, g_join = nullptr;
-
-SideStream::SideStream(hipStream_t main_stream) : main(main_stream), side(main_stream), active(false) {
-  static const bool disabled = [] { const char* e = getenv("MOBODY_NO_SIDE_STREAM"); return e && atoi(e) != 0; }();
-  if (disabled) return;
-  if (g_side == nullptr) {
-    if (hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking) != hipSuccess) { g_side = nullptr; return; }
-    if (hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&g_join, hipEventDisableTiming) != hipSuccess) { g_side = nullptr; return; }
-  }
-  if (hipEventRecord(g_fork, main) != hipSuccess) return;
-  if (hipStreamWaitEvent(g_side, g_fork, 0) != hipSuccess) return;
-  side = g_side;
-  active = true;
-}
-
-void SideStream::join() {
-  if (!active) return;
-  (void)hipEventRecord(g_join, side);
-  (void)hipStreamWaitEvent(main, g_join, 0);
-  active = false;
-}
-
 }  // namespace mobody
 
 using namespace mobody;
