@@ -8,10 +8,17 @@ import golden_util as gu
 from oracle import mobody_oracle as O
 from test_hip_train import Engine
 
-S, A, bs = 17, 6, 32
-cfg = gu.policy_cfg(S, A)
-pa, pq, pv = gu.policy_params(401, S, A)
-batch, n_true = gu.g7_batch(cfg, bs, S, A)
+# usage: diag_grad_error.py [S A N Nt]   (default: the golden g7 batch, bs=32)
+if len(sys.argv) == 5:
+    S, A, N, n_true = (int(x) for x in sys.argv[1:5])
+    cfg = gu.policy_cfg(S, A)
+    pa, pq, pv = gu.policy_params(91, S, A)
+    batch = gu.gi.batch(17, N, S, A)
+else:
+    S, A, bs = 17, 6, 32
+    cfg = gu.policy_cfg(S, A)
+    pa, pq, pv = gu.policy_params(401, S, A)
+    batch, n_true = gu.g7_batch(cfg, bs, S, A)
 st32 = O.TrainState(pa, pq, pv); o32 = O.train_step(st32, batch, n_true, cfg, apply=False)
 T32 = O.T
 O.T = lambda x, dtype=torch.float64: (x.to(torch.float64) if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x), dtype=torch.float64))
