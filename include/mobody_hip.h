@@ -143,8 +143,9 @@ int mobody_rollout_mask(const uint8_t* alive_in, const uint8_t* terminal, const 
 int mobody_sample_indices(uint32_t seed, uint32_t stream_id, const int64_t* counter, int64_t call_offset, int64_t n,
                           const int64_t* size, int32_t* out, void* stream);
 
-/* counter[0] += inc (device int64) */
-int mobody_counter_add(int64_t* counter, int64_t inc, void* stream);
+/* counter[i] += inc for i < n (device int64 words, n <= 64): one launch advances the RNG call id and both Adam
+ * step counts of a captured train() step */
+int mobody_counter_add(int64_t* counter, int n, int64_t inc, void* stream);
 
 /* ---- 3-layer MLP forward (ReLU) -------------------------------------------------------- */
 /* x = concat(src0[rows][n0], src1[rows][n1]) (src1 may be NULL), n0+n1 == in_dim.

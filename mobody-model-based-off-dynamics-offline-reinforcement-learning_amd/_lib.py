@@ -65,7 +65,7 @@ PROTOTYPES = {
     "mobody_termination": (C.c_int, [C.c_int, vp, i64, C.c_int, vp, vp]),
     "mobody_rollout_mask": (C.c_int, [vp, vp, vp, f32, C.c_int, i64, vp, vp, vp]),
     "mobody_sample_indices": (C.c_int, [u32, u32, vp, i64, i64, vp, vp, vp]),
-    "mobody_counter_add": (C.c_int, [vp, i64, vp]),
+    "mobody_counter_add": (C.c_int, [vp, C.c_int, i64, vp]),
     "mobody_mlp3_forward": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, i64, C.c_int, f32, vp,
                                       vp, vp, vp, vp]),
     "mobody_gather_batch": (C.c_int, [C.POINTER(MobodyBufferView), C.POINTER(vp), C.POINTER(i64), C.c_int, C.c_int,

@@ -356,7 +356,7 @@ class MOBODY(object):
         nf = int(cfg["fake_batch_scale"] * batch_size) if cfg["fake_batch_scale"] != 0 else 0
         N, Nt = ns + nt + nf, ns + nt
         c = self._ctr
-        ops.counter_add(c[0:1]); ops.counter_add(c[1:2]); ops.counter_add(c[2:3])
+        ops.counter_add(c)
         bufs, cnts, seeds = [src, tar], [ns, nt], [self.seed + 101, self.seed + 102]
         if nf > 0:
             bufs.append(self.fake_replay_buffer); cnts.append(nf); seeds.append(self.seed + 103)

@@ -284,13 +284,43 @@ __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
     const bool is_bias = (o >= a.L.b1 && o < a.L.b1 + HID) || (o >= a.L.b2 && o < a.L.b2 + HID) || (o >= a.L.b3);
     if (is_bias) return;
     float s = 0.f;
-    for (int k = 0; k < a.nsplit; ++k) s += a.slabs[(long long)k * a.slab_stride + j];
+    int k = 0;
+    for (; k + 4 <= a.nsplit; k += 4) {            // 4 independent loads in flight, summed in slab order
+      const float* p = a.slabs + (long long)k * a.slab_stride + j;
+      const float v0 = p[0], v1 = p[a.slab_stride], v2 = p[2 * a.slab_stride], v3 = p[3 * a.slab_stride];
+      s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; k < a.nsplit; ++k) s += a.slabs[(long long)k * a.slab_stride + j];
     a.grad[j] = s;
     return;
   }
   // ---- bias part: wave index -> (member, bias element) ----
   const int per = 2 * HID + a.L.Np3;
   const long long wv = (gid - ((nW + 255) / 256) * 256) >> 6;
+  if (blockIdx.x == gridDim.x - 1 && a.loss.kind != 0) {      // the extra workgroup: loss partials -> scalars
+    __shared__ float sm[8];
+    const LossFinal& f = a.loss;
+    const int stride = f.kind == 2 ? 2 : 1;
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = threadIdx.x; k < f.nparts; k += 256) { s0 += f.parts[stride * k]; if (f.kind == 2) s1 += f.parts[2 * k + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = s0; sm[4 + (threadIdx.x >> 6)] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s0 = sm[0] + sm[1] + sm[2] + sm[3];
+      s1 = sm[4] + sm[5] + sm[6] + sm[7];
+      if (f.kind == 1) {
+        f.out[0] = s0 * f.scale;
+      } else {
+        const float pw = f.scale_q ? f.weight / (f.stats[0] / f.ng) : 1.f;
+        const float bc = s1 / f.ntg_a;
+        f.out[0] = pw * s0 / f.ng + f.bc_coef * bc;
+        f.out[1] = bc;
+      }
+    }
+    return;
+  }
   if (wv < 0 || wv >= (long long)a.L.members * per) return;
   const int lane = threadIdx.x & 63;
   const int m = (int)(wv / per), off = (int)(wv % per);
@@ -307,7 +337,8 @@ __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
 int launch_grad_reduce(const GradReduceArgs& a, hipStream_t st) {
   const long long wblocks = cdiv(a.L.total_floats, 256);
   const long long bblocks = cdiv((long long)a.L.members * (2 * HID + a.L.Np3) * 64, 256);
-  hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(wblocks + bblocks)), dim3(256), 0, st, a);
+  const long long lblocks = a.loss.kind != 0 ? 1 : 0;
+  hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(wblocks + bblocks + lblocks)), dim3(256), 0, st, a);
   MB_LAUNCH_OK("k_grad_reduce");
   return 0;
 }

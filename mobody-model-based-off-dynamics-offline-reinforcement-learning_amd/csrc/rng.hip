@@ -43,7 +43,7 @@ __global__ void k_sample_indices(uint32_t seed, uint32_t sid, const long long* c
   const long long sz = size[0];
   out[i] = (int32_t)rng_index_at(seed, sid, call, (uint64_t)i, (uint32_t)(sz > 0 ? sz : 1));
 }
-__global__ void k_counter_add(long long* c, long long inc) { c[0] += inc; }
+__global__ void k_counter_add(long long* c, int n, long long inc) { if ((int)threadIdx.x < n) c[threadIdx.x] += inc; }
 }  // namespace mobody
 
 extern "C" int mobody_sample_indices(uint32_t seed, uint32_t stream_id, const int64_t* counter, int64_t call_offset, int64_t n,
@@ -57,9 +57,10 @@ extern "C" int mobody_sample_indices(uint32_t seed, uint32_t stream_id, const in
   return 0;
 }
 
-extern "C" int mobody_counter_add(int64_t* counter, int64_t inc, void* stream) {
+extern "C" int mobody_counter_add(int64_t* counter, int n, int64_t inc, void* stream) {
   MB_REQUIRE(counter, "mobody_counter_add: null pointer");
-  hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, as_stream(stream), (long long*)counter, (long long)inc);
+  MB_REQUIRE(n >= 1 && n <= 64, "mobody_counter_add: n=%d outside 1..64", n);
+  hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(64), 0, as_stream(stream), (long long*)counter, n, (long long)inc);
   MB_LAUNCH_OK("k_counter_add");
   return 0;
 }

@@ -36,11 +36,22 @@ struct WgradArgs {
 };
 int launch_wgrad(WgradArgs a, hipStream_t st);
 
+// Final reduction of per-workgroup loss partials, done by one extra workgroup of k_grad_reduce (saves a launch).
+//   kind 1 (critic): out[0] = scale * sum parts[k]
+//   kind 2 (actor):  parts = pairs (sum -min q, sum w*(pi-a)^2);  bc = s1/ntg_a;
+//                    out[0] = p_w * s0 / ng + bc_coef * bc, out[1] = bc,  p_w = scale_q ? weight/(stats[0]/ng) : 1
+struct LossFinal {
+  int kind, nparts, scale_q;
+  float scale, weight, bc_coef, ng, ntg_a;
+  const float* parts; const float* stats; float* out;
+};
+
 struct GradReduceArgs {
   MobodyMlpLayout L;
   const float* slabs; long long slab_stride; int nsplit;
   const float* dbp; int ntiles;
   float* grad;
+  LossFinal loss;       // kind 0: none
 };
 int launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);
 

@@ -83,42 +83,49 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {      // blockDi
   return s;
 }
 
-// y = r + nd*gamma*min(Qt1,Qt2)(s',pi(s'));  dz3[m] = dL/dq_m = 2 (q_m - y) / N_global   (mobody.py:190-207)
+// y = r + nd*gamma*min(Qt1,Qt2)(s',pi(s'));  dz3[m] = dL/dq_m = 2 (q_m - y) / N_global   (mobody.py:190-207).
+// lossp[workgroup] = sum over its rows of (q1-y)^2 + (q2-y)^2; k_grad_reduce's extra workgroup finishes the loss.
 __global__ __launch_bounds__(256) void k_td_prep(const float* qt, const float* qnext, const float* q, const float* r,
                                                  const float* nd, long long N, float gamma, float invNg, int Np3,
-                                                 float* dz3) {
+                                                 float* dz3, float* lossp) {
+  __shared__ float sm[4];
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= N) return;
-  const float qn = qnext ? qnext[row] : fminf(qt[row], qt[N + row]);     // V(s') in the advantage variant (:215)
-  const float y = r[row] + nd[row] * gamma * qn;
-  for (int m = 0; m < 2; ++m) {
-    float* o = dz3 + (m * N + row) * Np3;
-    o[0] = 2.f * (q[m * N + row] - y) * invNg;
-    for (int c = 1; c < Np3; ++c) o[c] = 0.f;
-  }
-}
-
-__global__ __launch_bounds__(1024) void k_td_loss(const float* qt, const float* qnext, const float* q, const float* r,
-                                                  const float* nd, long long N, float gamma, float invNg, float* out) {
-  __shared__ float sm[16];
-  float s = 0.f;
-  for (long long row = threadIdx.x; row < N; row += blockDim.x) {
-    const float qn = qnext ? qnext[row] : fminf(qt[row], qt[N + row]);
+  float l = 0.f;
+  if (row < N) {
+    const float qn = qnext ? qnext[row] : fminf(qt[row], qt[N + row]);     // V(s') in the advantage variant (:215)
     const float y = r[row] + nd[row] * gamma * qn;
-    const float d0 = q[row] - y, d1 = q[N + row] - y;
-    s += d0 * d0 + d1 * d1;
+    for (int m = 0; m < 2; ++m) {
+      const float d = q[m * N + row] - y;
+      float* o = dz3 + (m * N + row) * Np3;
+      o[0] = 2.f * d * invNg;
+      for (int c = 1; c < Np3; ++c) o[c] = 0.f;
+      l += d * d;
+    }
   }
-  s = block_sum(s, sm);
-  if (threadIdx.x == 0) out[0] = s * invNg;       // mse(q1,y)+mse(q2,y), local share
+  l = block_sum(l, sm);
+  if (threadIdx.x == 0) lossp[blockIdx.x] = l;
 }
 
 // stats[0] = sum_rows |min(Q1,Q2)(s,pi(s))|, stats[1] = sum_{rows<Nt} |min(Q1,Q2)(s_t,a_t)|   (:318, :259)
 __global__ __launch_bounds__(1024) void k_actor_stats(const float* qp, const float* qb, long long N, long long Nt,
                                                       float* stats) {
   __shared__ float sm[16];
-  float s0 = 0.f, s1 = 0.f;
-  for (long long row = threadIdx.x; row < N; row += blockDim.x) s0 += fabsf(fminf(qp[row], qp[N + row]));
-  for (long long row = threadIdx.x; row < Nt; row += blockDim.x) s1 += fabsf(fminf(qb[row], qb[Nt + row]));
+  constexpr int U = 4;                            // 2U independent loads in flight; each thread still adds its rows in
+  float s0 = 0.f, s1 = 0.f;                       // increasing order, so the sums do not depend on U
+  for (long long base = threadIdx.x; base < N; base += U * 1024) {
+    float a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const long long r = base + u * 1024; const long long rc = r < N ? r : 0; a[u] = qp[rc]; b[u] = qp[N + rc]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (base + u * 1024 < N) s0 += fabsf(fminf(a[u], b[u]));
+  }
+  for (long long base = threadIdx.x; base < Nt; base += U * 1024) {
+    float a[U], b[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const long long r = base + u * 1024; const long long rc = r < Nt ? r : 0; a[u] = qb[rc]; b[u] = qb[Nt + rc]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (base + u * 1024 < Nt) s1 += fabsf(fminf(a[u], b[u]));
+  }
   s0 = block_sum(s0, sm);
   s1 = block_sum(s1, sm);
   if (threadIdx.x == 0) { stats[0] = s0; stats[1] = s1; }
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(256) void k_actor_prep(ActorRowArgs a) {
 }
 
 // dL/d(pre-tanh) of the actor: Q path (sum of both members' dx) + BC path on the first Nt rows.  Also emits the
-// per-workgroup partial sums of the two loss terms (sum -min q, sum w*(pi-a)^2) for k_actor_loss.
+// per-workgroup partial sums of the two loss terms (sum -min q, sum w*(pi-a)^2); k_grad_reduce finishes them.
 __global__ __launch_bounds__(256) void k_actor_dpi(ActorRowArgs a) {
   __shared__ float sm[4];
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,20 +194,6 @@ __global__ __launch_bounds__(256) void k_actor_dpi(ActorRowArgs a) {
   s0 = block_sum(s0, sm);
   s1 = block_sum(s1, sm);
   if (threadIdx.x == 0) { a.lossp[2 * blockIdx.x] = s0; a.lossp[2 * blockIdx.x + 1] = s1; }
-}
-
-// loss_out[0] = p_w*mean(-q) + bc_coef*L_BC, loss_out[1] = L_BC   (local shares of the global means)
-__global__ __launch_bounds__(256) void k_actor_loss(ActorRowArgs a, int nparts) {
-  __shared__ float sm[4];
-  float s0 = 0.f, s1 = 0.f;
-  for (int k = threadIdx.x; k < nparts; k += blockDim.x) { s0 += a.lossp[2 * k]; s1 += a.lossp[2 * k + 1]; }
-  s0 = block_sum(s0, sm);
-  s1 = block_sum(s1, sm);
-  if (threadIdx.x == 0) {
-    const float bc = s1 / ((float)a.Ntg * (float)a.A);
-    a.loss_out[0] = policy_weight(a) * s0 / (float)a.Ng + a.h.bc_coef * bc;
-    a.loss_out[1] = bc;
-  }
 }
 
 // expectile regression of V towards min target-Q (update_v_function, mobody.py:231-242; asymmetric_l2_loss :85-86):
@@ -327,7 +320,7 @@ static Mlp3FwdArgs fwd_args(const float* blob, const MobodyMlpLayout& L, const f
 // weight gradients of one packed MLP: one merged split-K launch + the deterministic reduction
 static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h1, const float* h2, const float* dz3,
                         const float* dz2, const float* dz1, long long rows, const TrainWs& w, float* grad,
-                        hipStream_t st) {
+                        const LossFinal& loss, hipStream_t st) {
   WgradArgs g{};
   g.rows = rows; g.slabs = w.slabs; g.slab_stride = w.slab_stride; g.out_mstride = L.member_floats;
   g.nsplit = w.nsplit; g.members = L.members;
@@ -340,7 +333,7 @@ static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h
   g.job[2] = WgradJob{dz3, rows * L.Np3, L.Np3, L.Np3, h2, hs, HID, HID, L.w3, L.Np3, L.Np3, HID, 1, 0, 0, 0};
   int rc = launch_wgrad(g, st);
   if (rc) return rc;
-  GradReduceArgs r{L, w.slabs, w.slab_stride, w.nsplit, w.dbp, w.ntiles, grad};
+  GradReduceArgs r{L, w.slabs, w.slab_stride, w.nsplit, w.dbp, w.ntiles, grad, loss};
   return launch_grad_reduce(r, st);
 }
 
@@ -391,13 +384,13 @@ extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h
   }   // else: q_next = V(s') supplied by the caller (update_q_functions_1, :210-229)
   if (rc) return rc;
   const float invNg = 1.f / (float)d->N_global;
-  hipLaunchKernelGGL(k_td_prep, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, w.qt, q_next, w.q, reward, not_done, N, h->gamma, invNg, w.Lq.Np3, w.dz3q);
+  hipLaunchKernelGGL(k_td_prep, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, w.qt, q_next, w.q, reward, not_done, N, h->gamma, invNg, w.Lq.Np3, w.dz3q, w.lossp);
   MB_LAUNCH_OK("k_td_prep");
-  hipLaunchKernelGGL(k_td_loss, dim3(1), dim3(1024), 0, st, w.qt, q_next, w.q, reward, not_done, N, h->gamma, invNg, loss_out);
-  MB_LAUNCH_OK("k_td_loss");
   rc = launch_mlp3_bwd(bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp), 2, false, w.tile_rows, st);
   if (rc) return rc;
-  return weight_grads(w.Lq, w.xq, w.h1q, w.h2q, w.dz3q, w.dz2, w.dz1, N, w, grad_q, st);
+  LossFinal lf{};                                  // q_loss = mse(q1,y)+mse(q2,y), local share of the global mean
+  lf.kind = 1; lf.nparts = (int)cdiv(N, 256); lf.scale = invNg; lf.parts = w.lossp; lf.out = loss_out;
+  return weight_grads(w.Lq, w.xq, w.h1q, w.h2q, w.dz3q, w.dz2, w.dz1, N, w, grad_q, lf, st);
 }
 
 extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
@@ -453,11 +446,12 @@ extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper
   if (rc) return rc;
   hipLaunchKernelGGL(k_actor_dpi, dim3(gb), dim3(256), 0, st, ra);
   MB_LAUNCH_OK("k_actor_dpi");
-  hipLaunchKernelGGL(k_actor_loss, dim3(1), dim3(256), 0, st, ra, (int)gb);
-  MB_LAUNCH_OK("k_actor_loss");
   rc = launch_mlp3_bwd(bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp), 1, false, w.tile_rows, st);
   if (rc) return rc;
-  return weight_grads(w.La, w.xa, w.h1a, w.h2a, w.dz3a, w.dz2, w.dz1, N, w, grad_actor, st);
+  LossFinal lf{};                                  // loss_out[0] = p_w*mean(-q) + bc_coef*L_BC, [1] = L_BC (local shares)
+  lf.kind = 2; lf.nparts = (int)gb; lf.scale_q = h->scale_q; lf.weight = h->weight; lf.bc_coef = h->bc_coef;
+  lf.ng = (float)ra.Ng; lf.ntg_a = (float)ra.Ntg * (float)ra.A; lf.parts = w.lossp; lf.stats = stats; lf.out = loss_out;
+  return weight_grads(w.La, w.xa, w.h1a, w.h2a, w.dz3a, w.dz2, w.dz1, N, w, grad_actor, lf, st);
 }
 
 extern "C" int mobody_mlp_transpose(int in_dim, int out_dim, int members, const float* blob, float* blob_T, void* stream) {

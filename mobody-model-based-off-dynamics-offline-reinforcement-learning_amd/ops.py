@@ -214,7 +214,8 @@ def sample_indices(seed, stream_id, counter, call_offset, n, size_dev, out=None)
 
 
 def counter_add(counter, inc=1):
-    check(load().mobody_counter_add(ptr(counter), inc, cur_stream()), "mobody_counter_add")
+    """counter: device int64[n]; every word += inc."""
+    check(load().mobody_counter_add(ptr(counter), counter.numel(), inc, cur_stream()), "mobody_counter_add")
 
 
 def par_penalty(next_state_true, next_state_model, reward, coef):
