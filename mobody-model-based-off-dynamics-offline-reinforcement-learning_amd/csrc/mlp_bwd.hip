@@ -58,8 +58,84 @@ __device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], flo
   cs[1] += __shfl_xor(cs[1], 32);
 }
 
+// Seed prologue (BwdSeed modes 1-3): fills Xs[r][0..Np3) for the TB rows of this tile.  All global loads of a pass
+// are independent (one round trip); the loss partials are reduced through `red` (static LDS, 8 floats).
+__device__ __forceinline__ void bwd_seed(const Mlp3BwdArgs& a, float* Xs, float* red, int m, long long row0, int rows_here,
+                                         int TB) {
+  const BwdSeed& sd = a.seed;
+  const int Np3 = a.Np3;
+  const int t = threadIdx.x;
+  float l0 = 0.f, l1 = 0.f;
+  if (sd.mode == 1 || sd.mode == 2) {
+    if (t < TB) {
+      const bool ok = t < rows_here;
+      const long long row = row0 + (ok ? t : 0);
+      float v = 0.f;
+      if (sd.mode == 1) {
+        const float qn = sd.qnext ? sd.qnext[row] : fminf(sd.qt[row], sd.qt[a.rows + row]);
+        const float y = sd.r[row] + sd.nd[row] * sd.gamma * qn;
+        const float d = sd.q[(long long)m * a.rows + row] - y;
+        v = ok ? 2.f * d * sd.inv_ng : 0.f;
+        l0 = ok ? d * d : 0.f;
+      } else {
+        const ActorRowArgs& r = sd.ar;
+        const float q0 = r.qp[row], q1 = r.qp[r.N + row];
+        const float c = -policy_weight(r) / (float)r.Ng;
+        const float g0 = q0 < q1 ? 1.f : (q0 == q1 ? 0.5f : 0.f);
+        v = ok ? c * (m == 0 ? g0 : 1.f - g0) : 0.f;
+        if (m == 0 && ok && row < r.Nt) r.bcw[row] = bc_weight(r, row);
+      }
+      float* o = Xs + t * LDX;
+      o[0] = v;
+      for (int c = 1; c < Np3; ++c) o[c] = 0.f;
+      if (sd.dz3_out != nullptr && ok) {
+        float* g = sd.dz3_out + ((long long)m * a.rows + row) * Np3;
+        g[0] = v;
+        for (int c = 1; c < Np3; ++c) g[c] = 0.f;
+      }
+    }
+  } else {                                          // mode 3: one thread per (row, column)
+    const ActorRowArgs& r = sd.ar;
+    const float wscale = r.h.bc_coef * 2.f / ((float)r.Ntg * (float)r.A);
+    for (int e = t; e < TB * Np3; e += NTHREADS) {
+      const int rr = e / Np3, j = e - rr * Np3;
+      const bool ok = rr < rows_here && j < r.A;
+      const long long row = row0 + (rr < rows_here ? rr : 0);
+      const int jc = j < r.A ? j : 0;
+      const bool bc = row < r.Nt;
+      const float p = r.pi[row * r.A + jc];
+      const float d0 = r.dxa[row * r.A + jc], d1 = r.dxa[(r.N + row) * r.A + jc];
+      const float act = r.act[row * r.A + jc];
+      const float w = r.bcw[bc ? row : 0];
+      float v = 0.f;
+      if (ok) {
+        float d = d0 + d1;
+        if (bc) { const float df = p - act; d += wscale * w * df; l1 += w * (df * df); }
+        const float th = p / r.h.max_action;
+        v = d * r.h.max_action * (1.f - th * th);                   // d tanh
+        if (j == 0) l0 = l0 - fminf(r.qp[row], r.qp[r.N + row]);
+      }
+      Xs[rr * LDX + j] = v;
+      if (rr < rows_here) sd.dz3_out[(row0 + rr) * Np3 + j] = v;
+    }
+  }
+  if (sd.mode == 2) return;
+  // loss partials of this tile
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { l0 += __shfl_xor(l0, o); l1 += __shfl_xor(l1, o); }
+  if ((t & 63) == 0) { red[t >> 6] = l0; red[4 + (t >> 6)] = l1; }
+  __syncthreads();
+  if (t == 0) {
+    l0 = red[0] + red[1] + red[2] + red[3];
+    l1 = red[4] + red[5] + red[6] + red[7];
+    if (sd.mode == 1) sd.lossp[blockIdx.x * 2 + m] = l0;
+    else { sd.lossp[2 * blockIdx.x] = l0; sd.lossp[2 * blockIdx.x + 1] = l1; }
+  }
+}
+
 template <bool DX, int MT>
 __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
+  __shared__ float red[8];
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   constexpr int TB = 32 * MT;
   const int m = blockIdx.y;
@@ -75,7 +151,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   float* dz1 = a.dz1 ? a.dz1 + ((long long)m * a.rows + row0) * HID : nullptr;
   float* dbp = a.dbp + ((long long)blockIdx.x * gridDim.y + m) * (2 * HID + a.Np3);
 
-  tile_load(Xs, 0, a.dz3 + ((long long)m * a.rows + row0) * a.Np3, a.Np3, a.Np3, 0, rows_here, TB);
+  if (a.seed.mode == 0) tile_load(Xs, 0, a.dz3 + ((long long)m * a.rows + row0) * a.Np3, a.Np3, a.Np3, 0, rows_here, TB);
+  else bwd_seed(a, Xs, red, m, row0, rows_here, TB);
   lds_barrier();
   if ((int)threadIdx.x < a.Np3) {                 // db3 partial of this tile
     float s = 0.f;

@@ -4,8 +4,48 @@
 
 namespace mobody {
 
+// Row-wise quantities of the actor update (mobody.py:246-276, 314-345) shared by the seed prologues of k_mlp3_bwd.
+struct ActorRowArgs {
+  const float *qp, *qb, *stats, *pi, *act, *dxa;
+  const float* v_true;       // [Nt] V(s_true) when config['advantage'] (else null)
+  float* bcw;                // [Nt] BC weights (written by the frozen-Q backward, read by the actor backward)
+  long long N, Nt, Ng, Ntg;
+  int A;
+  MobodyHyper h;
+};
+__device__ __forceinline__ float policy_weight(const ActorRowArgs& a) {       // p_w, mobody.py:318 / :283
+  return a.h.scale_q ? a.h.weight / (a.stats[0] / (float)a.Ng) : 1.f;
+}
+__device__ __forceinline__ float bc_weight(const ActorRowArgs& a, long long row) {   // exp_adv, :257-267
+  if (!a.h.q_weighted) return 1.f;
+  const float qb = fminf(a.qb[row], a.qb[a.Nt + row]);
+  const float adv = a.v_true ? qb - a.v_true[row]                      // advantage variant, mobody.py:255-256
+                             : qb / (a.stats[1] / (float)a.Ntg);
+  return fminf(expf(3.f * adv), 100.f);
+}
+
+// Where the output-layer gradient dz3 of a backward launch comes from.  Modes 1-3 compute it in the kernel's
+// prologue from the row-wise inputs (no separate row-wise launch, no dz3 round trip through HBM before the first GEMM):
+//   0  dz3 read from memory
+//   1  critic: y = r + nd*gamma*min(Qt1,Qt2) (or q_next); dz3[m][row][0] = 2 (q_m - y) / N_global   (mobody.py:190-207)
+//      lossp[tile*2 + m] = sum_rows (q_m - y)^2
+//   2  frozen twin-Q of the actor update: dz3[m][row][0] = -p_w/N_global * d min(q0,q1)/dq_m (ties split 1/2, as
+//      torch.min's backward); member 0 also writes the BC weights bcw[row < Nt]
+//   3  actor: d(pre-tanh) = (dxa[0]+dxa[1] + bc_coef*2*w*(pi-a)/(Ntg*A)) * max_action*(1-tanh^2);
+//      lossp[2*tile] = sum -min q, lossp[2*tile+1] = sum w*(pi-a)^2
+// Modes 1 and 3 also store dz3 to `dz3_out` (the weight-gradient GEMM reads it).
+struct BwdSeed {
+  int mode;
+  const float *q, *qt, *qnext, *r, *nd;      // mode 1 ([2][rows] q and qt, [rows] the rest)
+  float gamma, inv_ng;
+  ActorRowArgs ar;                           // modes 2, 3
+  float* dz3_out;
+  float* lossp;
+};
+
 struct Mlp3BwdArgs {
-  const float* dz3;        // [members][rows][Np3] (zero in padded columns)
+  BwdSeed seed;
+  const float* dz3;        // [members][rows][Np3] (zero in padded columns); seed.mode 0 only
   const float* h1;         // [members][rows][256] post-ReLU hidden activations saved by the forward
   const float* h2;
   const float* wt;         // transposed blob (member 0)

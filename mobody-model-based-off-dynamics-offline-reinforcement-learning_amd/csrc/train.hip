@@ -47,7 +47,7 @@ static int carve(const MobodyTrainDims& d, float* base, TrainWs& w) {
   w.dz3a = take(N * w.La.Np3);
   w.dxa = take(2 * N * d.A);
   w.bcw = take(Nt > 0 ? Nt : 1);
-  w.lossp = take(2 * cdiv(N, 256));
+  w.lossp = take(2 * cdiv(N, 32));                // per (row tile, member) / per-tile pairs, tiles of >= 32 rows
   w.tile_rows = pick_tile_rows(N, 1);             // one value for both nets: the bias partials are per row tile
   w.ntiles = (int)cdiv(N, w.tile_rows);
   w.nsplit = wgrad_nsplit(N);
@@ -83,29 +83,6 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {      // blockDi
   return s;
 }
 
-// y = r + nd*gamma*min(Qt1,Qt2)(s',pi(s'));  dz3[m] = dL/dq_m = 2 (q_m - y) / N_global   (mobody.py:190-207).
-// lossp[workgroup] = sum over its rows of (q1-y)^2 + (q2-y)^2; k_grad_reduce's extra workgroup finishes the loss.
-__global__ __launch_bounds__(256) void k_td_prep(const float* qt, const float* qnext, const float* q, const float* r,
-                                                 const float* nd, long long N, float gamma, float invNg, int Np3,
-                                                 float* dz3, float* lossp) {
-  __shared__ float sm[4];
-  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  float l = 0.f;
-  if (row < N) {
-    const float qn = qnext ? qnext[row] : fminf(qt[row], qt[N + row]);     // V(s') in the advantage variant (:215)
-    const float y = r[row] + nd[row] * gamma * qn;
-    for (int m = 0; m < 2; ++m) {
-      const float d = q[m * N + row] - y;
-      float* o = dz3 + (m * N + row) * Np3;
-      o[0] = 2.f * d * invNg;
-      for (int c = 1; c < Np3; ++c) o[c] = 0.f;
-      l += d * d;
-    }
-  }
-  l = block_sum(l, sm);
-  if (threadIdx.x == 0) lossp[blockIdx.x] = l;
-}
-
 // stats[0] = sum_rows |min(Q1,Q2)(s,pi(s))|, stats[1] = sum_{rows<Nt} |min(Q1,Q2)(s_t,a_t)|   (:318, :259)
 __global__ __launch_bounds__(1024) void k_actor_stats(const float* qp, const float* qb, long long N, long long Nt,
                                                       float* stats) {
@@ -129,71 +106,6 @@ __global__ __launch_bounds__(1024) void k_actor_stats(const float* qp, const flo
   s0 = block_sum(s0, sm);
   s1 = block_sum(s1, sm);
   if (threadIdx.x == 0) { stats[0] = s0; stats[1] = s1; }
-}
-
-struct ActorRowArgs {
-  const float *qp, *qb, *stats, *pi, *act, *dxa;
-  const float* v_true;       // [Nt] V(s_true) when config['advantage'] (else null)
-  float *dz3q, *bcw, *dz3a, *loss_out, *lossp;
-  long long N, Nt, Ng, Ntg;
-  int A, Np3q, Np3a;
-  MobodyHyper h;
-};
-
-__device__ __forceinline__ float policy_weight(const ActorRowArgs& a) {       // p_w, mobody.py:318 / :283
-  return a.h.scale_q ? a.h.weight / (a.stats[0] / (float)a.Ng) : 1.f;
-}
-__device__ __forceinline__ float bc_weight(const ActorRowArgs& a, long long row) {   // exp_adv, :257-267
-  if (!a.h.q_weighted) return 1.f;
-  const float qb = fminf(a.qb[row], a.qb[a.Nt + row]);
-  const float adv = a.v_true ? qb - a.v_true[row]                      // advantage variant, mobody.py:255-256
-                             : qb / (a.stats[1] / (float)a.Ntg);
-  return fminf(expf(3.f * adv), 100.f);
-}
-
-// d(-p_w*mean q)/dq_m routed through torch.min's subgradient (ties split 1/2), and the BC weights.
-__global__ __launch_bounds__(256) void k_actor_prep(ActorRowArgs a) {
-  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= a.N) return;
-  const float q0 = a.qp[row], q1 = a.qp[a.N + row];
-  const float c = -policy_weight(a) / (float)a.Ng;
-  const float g0 = q0 < q1 ? 1.f : (q0 == q1 ? 0.5f : 0.f);
-  float* o0 = a.dz3q + row * a.Np3q;
-  float* o1 = a.dz3q + (a.N + row) * a.Np3q;
-  o0[0] = c * g0;
-  o1[0] = c * (1.f - g0);
-  for (int k = 1; k < a.Np3q; ++k) { o0[k] = 0.f; o1[k] = 0.f; }
-  if (row < a.Nt) a.bcw[row] = bc_weight(a, row);
-}
-
-// dL/d(pre-tanh) of the actor: Q path (sum of both members' dx) + BC path on the first Nt rows.  Also emits the
-// per-workgroup partial sums of the two loss terms (sum -min q, sum w*(pi-a)^2); k_grad_reduce finishes them.
-__global__ __launch_bounds__(256) void k_actor_dpi(ActorRowArgs a) {
-  __shared__ float sm[4];
-  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  float s0 = 0.f, s1 = 0.f;
-  if (row < a.N) {
-    const float w = row < a.Nt ? a.bcw[row] : 0.f;
-    const float wbc = a.h.bc_coef * 2.f * w / ((float)a.Ntg * (float)a.A);
-    float* o = a.dz3a + row * a.Np3a;
-    float e = 0.f;
-    for (int j = 0; j < a.Np3a; ++j) {
-      float v = 0.f;
-      if (j < a.A) {
-        const float p = a.pi[row * a.A + j];
-        float d = a.dxa[row * a.A + j] + a.dxa[(a.N + row) * a.A + j];
-        if (row < a.Nt) { const float df = p - a.act[row * a.A + j]; d += wbc * df; e += df * df; }
-        const float t = p / a.h.max_action;
-        v = d * a.h.max_action * (1.f - t * t);                   // d tanh
-      }
-      o[j] = v;
-    }
-    s0 = -fminf(a.qp[row], a.qp[a.N + row]);
-    s1 = w * e;
-  }
-  s0 = block_sum(s0, sm);
-  s1 = block_sum(s1, sm);
-  if (threadIdx.x == 0) { a.lossp[2 * blockIdx.x] = s0; a.lossp[2 * blockIdx.x + 1] = s1; }
 }
 
 // expectile regression of V towards min target-Q (update_v_function, mobody.py:231-242; asymmetric_l2_loss :85-86):
@@ -384,12 +296,14 @@ extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h
   }   // else: q_next = V(s') supplied by the caller (update_q_functions_1, :210-229)
   if (rc) return rc;
   const float invNg = 1.f / (float)d->N_global;
-  hipLaunchKernelGGL(k_td_prep, dim3((unsigned)cdiv(N, 256)), dim3(256), 0, st, w.qt, q_next, w.q, reward, not_done, N, h->gamma, invNg, w.Lq.Np3, w.dz3q, w.lossp);
-  MB_LAUNCH_OK("k_td_prep");
-  rc = launch_mlp3_bwd(bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp), 2, false, w.tile_rows, st);
+  // TD error -> dz3 in the backward's prologue (mobody.py:190-207), then dz2, dz1 and the bias partials
+  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp);
+  bq.seed.mode = 1; bq.seed.q = w.q; bq.seed.qt = w.qt; bq.seed.qnext = q_next; bq.seed.r = reward; bq.seed.nd = not_done;
+  bq.seed.gamma = h->gamma; bq.seed.inv_ng = invNg; bq.seed.dz3_out = w.dz3q; bq.seed.lossp = w.lossp;
+  rc = launch_mlp3_bwd(bq, 2, false, w.tile_rows, st);
   if (rc) return rc;
   LossFinal lf{};                                  // q_loss = mse(q1,y)+mse(q2,y), local share of the global mean
-  lf.kind = 1; lf.nparts = (int)cdiv(N, 256); lf.scale = invNg; lf.parts = w.lossp; lf.out = loss_out;
+  lf.kind = 1; lf.nparts = 2 * w.ntiles; lf.scale = invNg; lf.parts = w.lossp; lf.out = loss_out;
   return weight_grads(w.Lq, w.xq, w.h1q, w.h2q, w.dz3q, w.dz2, w.dz1, N, w, grad_q, lf, st);
 }
 
@@ -433,23 +347,22 @@ extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper
   const long long N = d->N;
   ActorRowArgs ra{};
   ra.qp = w.q; ra.qb = w.qb; ra.stats = stats; ra.pi = w.pi; ra.act = action; ra.dxa = w.dxa; ra.v_true = v_true;
-  ra.dz3q = w.dz3q; ra.bcw = w.bcw; ra.dz3a = w.dz3a; ra.loss_out = loss_out; ra.lossp = w.lossp;
-  ra.N = N; ra.Nt = d->Nt; ra.Ng = d->N_global; ra.Ntg = d->Nt_global > 0 ? d->Nt_global : 1;
-  ra.A = d->A; ra.Np3q = w.Lq.Np3; ra.Np3a = w.La.Np3; ra.h = *h;
-  const unsigned gb = (unsigned)cdiv(N, 256);
-  hipLaunchKernelGGL(k_actor_prep, dim3(gb), dim3(256), 0, st, ra);
-  MB_LAUNCH_OK("k_actor_prep");
-  // dq -> d(action) through the frozen twin-Q (parameters get no gradient, mobody.py:555-556)
-  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, nullptr, nullptr, w.dbp);
+  ra.bcw = w.bcw; ra.N = N; ra.Nt = d->Nt; ra.Ng = d->N_global; ra.Ntg = d->Nt_global > 0 ? d->Nt_global : 1;
+  ra.A = d->A; ra.h = *h;
+  // dq -> d(action) through the frozen twin-Q (parameters get no gradient, mobody.py:555-556); the prologue forms
+  // -p_w/N d min(q1,q2) and the BC weights
+  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, nullptr, w.h1q, w.h2q, N, nullptr, nullptr, w.dbp);
+  bq.seed.mode = 2; bq.seed.ar = ra;
   bq.dx = w.dxa; bq.dx_c0 = d->S; bq.dx_n = d->A;
   rc = launch_mlp3_bwd(bq, 2, true, w.tile_rows, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_actor_dpi, dim3(gb), dim3(256), 0, st, ra);
-  MB_LAUNCH_OK("k_actor_dpi");
-  rc = launch_mlp3_bwd(bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp), 1, false, w.tile_rows, st);
+  // actor: d(pre-tanh) from both members' dx and the BC term in the prologue, then the actor's own backward
+  Mlp3BwdArgs ba = bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp);
+  ba.seed.mode = 3; ba.seed.ar = ra; ba.seed.dz3_out = w.dz3a; ba.seed.lossp = w.lossp;
+  rc = launch_mlp3_bwd(ba, 1, false, w.tile_rows, st);
   if (rc) return rc;
   LossFinal lf{};                                  // loss_out[0] = p_w*mean(-q) + bc_coef*L_BC, [1] = L_BC (local shares)
-  lf.kind = 2; lf.nparts = (int)gb; lf.scale_q = h->scale_q; lf.weight = h->weight; lf.bc_coef = h->bc_coef;
+  lf.kind = 2; lf.nparts = w.ntiles; lf.scale_q = h->scale_q; lf.weight = h->weight; lf.bc_coef = h->bc_coef;
   lf.ng = (float)ra.Ng; lf.ntg_a = (float)ra.Ntg * (float)ra.A; lf.parts = w.lossp; lf.stats = stats; lf.out = loss_out;
   return weight_grads(w.La, w.xa, w.h1a, w.h2a, w.dz3a, w.dz2, w.dz1, N, w, grad_actor, lf, st);
 }
