@@ -11,21 +11,33 @@
 namespace mobody {
 
 // One hidden layer in place on the LDS image: X <- act(X[:, :Kp] * W + b); `extra(row, col, y)` sees every output.
-template <int ACT, int MT = 2, class Extra>
+// `ring` holds wide_prefetch(W, Kp); `between()` runs after the last MFMA and before the epilogue -- the place to
+// request the NEXT layer's first weight fragments (the ring's registers are free again), so their L2/HBM round trip
+// overlaps this layer's barrier + epilogue instead of stalling the next GEMM.
+template <int ACT, int MT = 2, class Extra, class Between>
 __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ W, const float* __restrict__ b, int Kp,
-                                           Extra&& extra) {
+                                           WideRing& ring, Extra&& extra, Between&& between) {
+  // the wave's two bias values (columns 64w + 32nt + lane&31): requested before the GEMM, consumed after it
+  const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
   f32x16 acc[MT][2];
   wide_zero<MT>(acc);
-  wide_gemm<MT>(Xs, W, Kp, acc);
+  wide_gemm<MT>(Xs, W, Kp, acc, ring);
+  between();
   lds_barrier();                         // every wave has finished reading the old image
-  // the wave's two bias values (columns 64w + 32nt + lane&31) are fetched once, not per accumulator element
-  const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
   wide_foreach<MT>(acc, [&](int row, int col, float v) {
     const float y = activate<ACT>(v + ((col & 32) ? bias1 : bias0));
     Xs[row * LDX + col] = y;
     extra(row, col, y);
   });
   lds_barrier();
+}
+
+template <int ACT, int MT = 2, class Extra>
+__device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ W, const float* __restrict__ b, int Kp,
+                                           Extra&& extra) {
+  WideRing ring;
+  wide_prefetch(W, Kp, ring);
+  wide_layer<ACT, MT>(Xs, W, b, Kp, ring, extra, [] {});
 }
 
 struct NoExtra {
@@ -50,6 +62,7 @@ struct Mlp3FwdArgs {
 };
 
 int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stream);
+int launch_mlp3_fwd_pair(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, hipStream_t stream);
 
 // Row-tile height of the fused MLP kernels.  Measured on MI355X (bench.py, S=17/A=6): 32-row tiles (33 KB LDS,
 // ~124 VGPRs -> 4 workgroups = 16 waves per CU) beat 64-row tiles (2 workgroups per CU) at every batch size from

@@ -133,7 +133,9 @@ __device__ __forceinline__ void bwd_seed(const Mlp3BwdArgs& a, float* Xs, float*
   }
 }
 
-template <bool DX, int MT>
+// NT (DX only): 16-column tiles of the input-gradient layer handled by the K-split narrow layer (Np1t == 16*NT),
+// or 0 = any Np1t through the row-split path.
+template <bool DX, int MT, int NT>
 __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   __shared__ float red[8];
   extern __shared__ __attribute__((aligned(16))) float Xs[];
@@ -151,6 +153,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   float* dz1 = a.dz1 ? a.dz1 + ((long long)m * a.rows + row0) * HID : nullptr;
   float* dbp = a.dbp + ((long long)blockIdx.x * gridDim.y + m) * (2 * HID + a.Np3);
 
+  WideRing ring;
+  wide_prefetch(w3t, a.Np3, ring);                // weight fragments travel while the seed rows are fetched
   if (a.seed.mode == 0) tile_load(Xs, 0, a.dz3 + ((long long)m * a.rows + row0) * a.Np3, a.Np3, a.Np3, 0, rows_here, TB);
   else bwd_seed(a, Xs, red, m, row0, rows_here, TB);
   lds_barrier();
@@ -164,39 +168,44 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   float cs[2];
   // dh2 = dz3 * W3^T ; dz2 = dh2 * [h2 > 0]
   wide_zero<MT>(acc);
-  wide_gemm<MT>(Xs, w3t, a.Np3, acc);
+  wide_gemm<MT>(Xs, w3t, a.Np3, acc, ring);
+  wide_prefetch(w2t, HID, ring);                  // next layer's first fragments overlap the mask epilogue
   lds_barrier();
   wide_mask_store_colsum<MT>(acc, Xs, h2, dz2, rows_here, cs);
   if (lane < 32) { dbp[HID + 64 * w + lane] = cs[0]; dbp[HID + 64 * w + 32 + lane] = cs[1]; }
   lds_barrier();
   // dh1 = dz2 * W2^T ; dz1 = dh1 * [h1 > 0]
   wide_zero<MT>(acc);
-  wide_gemm<MT>(Xs, w2t, HID, acc);
+  wide_gemm<MT>(Xs, w2t, HID, acc, ring);
+  NarrowRegs<(NT > 0 ? NT : 1)> br;
+  if constexpr (DX && NT > 0) narrow_prefetch<NT>(w1t, 16 * NT, br);
   lds_barrier();
   wide_mask_store_colsum<MT>(acc, Xs, h1, dz1, rows_here, cs);
   if (lane < 32) { dbp[64 * w + lane] = cs[0]; dbp[64 * w + 32 + lane] = cs[1]; }
-  if (DX) {
+  if constexpr (DX) {
     lds_barrier();
     float* dx = a.dx + ((long long)m * a.rows + row0) * a.dx_n;
-    narrow_layer(Xs, w1t, HID, a.Np1t, [&](int row, int col, float v) {
+    auto emit = [&](int row, int col, float v) {
       const int c = col - a.dx_c0;
       if (row < rows_here && c >= 0 && c < a.dx_n) dx[row * a.dx_n + c] = v;
-    }, TB);
+    };
+    if constexpr (NT > 0) narrow_run<TB / 16, NT>(Xs, br, emit);
+    else narrow_layer(Xs, w1t, HID, a.Np1t, emit, TB);
   }
 }
 
-template <bool DX, int MT>
+template <bool DX, int MT, int NT>
 static int launch_bwd_t(const Mlp3BwdArgs& a, int members, hipStream_t st) {
   constexpr size_t lds = (size_t)32 * MT * LDX * sizeof(float);
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_mlp3_bwd<DX, MT>, lds);
+    int rc = allow_big_lds(k_mlp3_bwd<DX, MT, NT>, lds);
     if (rc) return rc;
     once = true;
   }
   dim3 grid((unsigned)cdiv(a.rows, 32 * MT), (unsigned)members);
   ProfScope prof(PROF_MLP_BWD, st);
-  hipLaunchKernelGGL((k_mlp3_bwd<DX, MT>), grid, dim3(NTHREADS), lds, st, a);
+  hipLaunchKernelGGL((k_mlp3_bwd<DX, MT, NT>), grid, dim3(NTHREADS), lds, st, a);
   MB_LAUNCH_OK("k_mlp3_bwd");
   return 0;
 }
@@ -204,8 +213,15 @@ static int launch_bwd_t(const Mlp3BwdArgs& a, int members, hipStream_t st) {
 // tile_rows (32 or 64) must be the value the caller sized `dbp` / the bias reduction with
 int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, int tile_rows, hipStream_t st) {
   if (a.rows <= 0) return 0;
-  if (tile_rows == 32) return with_dx ? launch_bwd_t<true, 1>(a, members, st) : launch_bwd_t<false, 1>(a, members, st);
-  return with_dx ? launch_bwd_t<true, 2>(a, members, st) : launch_bwd_t<false, 2>(a, members, st);
+  const int nt = a.Np1t == 16 ? 1 : a.Np1t == 32 ? 2 : 0;
+  if (tile_rows == 32) {
+    if (!with_dx) return launch_bwd_t<false, 1, 0>(a, members, st);
+    return nt == 1 ? launch_bwd_t<true, 1, 1>(a, members, st) : nt == 2 ? launch_bwd_t<true, 1, 2>(a, members, st)
+                                                                         : launch_bwd_t<true, 1, 0>(a, members, st);
+  }
+  if (!with_dx) return launch_bwd_t<false, 2, 0>(a, members, st);
+  return nt == 1 ? launch_bwd_t<true, 2, 1>(a, members, st) : nt == 2 ? launch_bwd_t<true, 2, 2>(a, members, st)
+                                                                       : launch_bwd_t<true, 2, 0>(a, members, st);
 }
 
 // ------------------------------------------------------------------------------------------------

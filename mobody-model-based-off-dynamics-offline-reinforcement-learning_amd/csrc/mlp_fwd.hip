@@ -10,13 +10,50 @@
 
 namespace mobody {
 
-template <int ACT, int MT, int RG>
-__global__ __launch_bounds__(NTHREADS * RG, 2) void k_mlp3_fwd(Mlp3FwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float Xs[];
+// Output layer of the forward (256 -> nout <= 16*NT) through the K-split narrow layer; NT = 0: generic row-split path.
+template <int ACT, int MT, int RG, int NT>
+__device__ __forceinline__ void mlp3_fwd_tail(const Mlp3FwdArgs& a, int m, float* Xs, WideRing& ring, float* h2,
+                                              long long row0, int rows_here) {
+  constexpr int TB = 32 * MT * RG;
+  const float* w3 = a.w3 + m * a.sw3;
+  const float* b3 = a.b3 + m * a.sb3;
+  float* out = a.out + m * a.out_mstride + row0 * a.out_ld;
+  auto save_h2 = [=](int row, int col, float y) {
+    if (h2 != nullptr && row < rows_here) h2[row * HID + col] = y;
+  };
+  auto emit = [&](int row, int col, float v, float bias) {
+    if (row < rows_here && col < a.nout) {
+      float y = v + bias;
+      if (a.out_mode == 1) y = a.max_action * tanhf(y);
+      out[row * a.out_ld + col] = y;
+    }
+  };
+  if constexpr (NT > 0) {
+    NarrowRegs<NT> br;
+    // b3 of this thread's output columns: element e = threadIdx.x + 256 k has column e % (16 NT), the same for all k
+    const int mycol = threadIdx.x % (16 * NT);
+    float bias;
+    wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [&] {
+      narrow_prefetch<NT>(w3, 16 * NT, br);
+      bias = b3[mycol < a.nout ? mycol : 0];
+    });
+    narrow_run<TB / 16, NT>(Xs, br, [&](int row, int col, float v) { emit(row, col, v, bias); });
+  } else {
+    wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [] {});
+    narrow_layer(Xs, w3, HID, a.Np3, [&](int row, int col, float v) { emit(row, col, v, b3[col < a.nout ? col : 0]); }, TB);
+  }
+}
+
+// NT: 16-column tiles of the output layer handled by the K-split narrow layer (Np3 == 16*NT), or 0 = any Np3.
+template <int ACT, int MT, int RG, int NT>
+__device__ __forceinline__ void mlp3_fwd_tile(const Mlp3FwdArgs& a, int m, float* Xs) {
   constexpr int TB = 32 * MT * RG;                // rows of this workgroup's tile
-  const int m = blockIdx.y;
   const long long row0 = (long long)blockIdx.x * TB;
   const int rows_here = (int)min((long long)TB, a.rows - row0);
+  const float* w1 = a.w1 + m * a.sw1;
+  const float* w2 = a.w2 + m * a.sw2;
+  WideRing ring;
+  wide_prefetch(w1, a.Kp1, ring);                 // W1 fragments travel while the input tile is fetched
 
   // ---- input tile: concat(src0, src1, src2), zero padded to Kp1 columns ----
   int c0 = 0;
@@ -38,51 +75,103 @@ __global__ __launch_bounds__(NTHREADS * RG, 2) void k_mlp3_fwd(Mlp3FwdArgs a) {
 
   float* h1 = a.save_h1 ? a.save_h1 + ((long long)m * a.rows + row0) * HID : nullptr;
   float* h2 = a.save_h2 ? a.save_h2 + ((long long)m * a.rows + row0) * HID : nullptr;
-  auto saver = [&](float* dst) {
-    return [=](int row, int col, float y) {
-      if (dst != nullptr && row < rows_here) dst[row * HID + col] = y;
-    };
-  };
-  wide_layer<ACT, MT>(Xs, a.w1 + m * a.sw1, a.b1 + m * a.sb1, a.Kp1, saver(h1));
-  wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, saver(h2));
-
-  const float* b3 = a.b3 + m * a.sb3;
-  float* out = a.out + m * a.out_mstride + row0 * a.out_ld;
-  narrow_layer(Xs, a.w3 + m * a.sw3, HID, a.Np3, [&](int row, int col, float v) {
-    if (row < rows_here && col < a.nout) {
-      float y = v + b3[col];
-      if (a.out_mode == 1) y = a.max_action * tanhf(y);
-      out[row * a.out_ld + col] = y;
-    }
-  }, TB);
+  wide_layer<ACT, MT>(Xs, w1, a.b1 + m * a.sb1, a.Kp1, ring,
+                      [=](int row, int col, float y) { if (h1 != nullptr && row < rows_here) h1[row * HID + col] = y; },
+                      [&] { wide_prefetch(w2, HID, ring); });
+  mlp3_fwd_tail<ACT, MT, RG, NT>(a, m, Xs, ring, h2, row0, rows_here);
 }
 
-template <int ACT, int MT, int RG>
+template <int ACT, int MT, int RG, int NT>
+__global__ __launch_bounds__(NTHREADS * RG, 2) void k_mlp3_fwd(Mlp3FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float Xs[];
+  mlp3_fwd_tile<ACT, MT, RG, NT>(a, blockIdx.y, Xs);
+}
+
+// Two independent networks in ONE launch (blockIdx.y < members_a -> net a, else net b): Q(s,a) with pi(s') in the
+// critic phase, Q(s_t,a_t) with pi(s) in the actor phase.  A 1-member launch of 10 k rows is only 320 workgroups
+// (1.25 per CU: half the chip idles through the second round); merged with the twin-Q launch the grid is ~3.5
+// workgroups per CU and one generation shorter.  The argument block is SELECTED (scalar selects), not branched on:
+// two inlined copies of the tile body in an if/else made hipcc keep both live (190 VGPRs, half the occupancy).
+template <int ACT, int MT, int NT>
+__global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_fwd2(Mlp3FwdArgs a, Mlp3FwdArgs b, int members_a) {
+  extern __shared__ __attribute__((aligned(16))) float Xs[];
+  const bool second = (int)blockIdx.y >= members_a;
+  const Mlp3FwdArgs s = second ? b : a;
+  if ((long long)blockIdx.x * (32 * MT) >= s.rows) return;       // the two nets may differ in rows (grid.x = max)
+  mlp3_fwd_tile<ACT, MT, 1, NT>(s, second ? (int)blockIdx.y - members_a : (int)blockIdx.y, Xs);
+}
+
+template <int ACT, int MT, int RG, int NT>
 static int launch_fwd_t(const Mlp3FwdArgs& a, int members, hipStream_t stream) {
   size_t lds = (size_t)32 * MT * RG * LDX * sizeof(float);
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_mlp3_fwd<ACT, MT, RG>, 160 * 1024);
+    int rc = allow_big_lds(k_mlp3_fwd<ACT, MT, RG, NT>, 160 * 1024);
     if (rc) return rc;
     once = true;
   }
   dim3 grid((unsigned)cdiv(a.rows, 32 * MT * RG), (unsigned)members);
   ProfScope prof(PROF_MLP_FWD, stream);
-  hipLaunchKernelGGL((k_mlp3_fwd<ACT, MT, RG>), grid, dim3(NTHREADS * RG), lds, stream, a);
+  hipLaunchKernelGGL((k_mlp3_fwd<ACT, MT, RG, NT>), grid, dim3(NTHREADS * RG), lds, stream, a);
   MB_LAUNCH_OK("k_mlp3_fwd");
   return 0;
 }
 
+template <int MT, int NT>
+static int launch_fwd2_t(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, hipStream_t stream) {
+  size_t lds = (size_t)32 * MT * LDX * sizeof(float);
+  static bool once = false;
+  if (!once) {
+    int rc = allow_big_lds(k_mlp3_fwd2<ACT_RELU, MT, NT>, 160 * 1024);
+    if (rc) return rc;
+    once = true;
+  }
+  const long long rows = a.rows > b.rows ? a.rows : b.rows;
+  dim3 grid((unsigned)cdiv(rows, 32 * MT), (unsigned)(members_a + members_b));
+  ProfScope prof(PROF_MLP_FWD, stream);
+  hipLaunchKernelGGL((k_mlp3_fwd2<ACT_RELU, MT, NT>), grid, dim3(NTHREADS), lds, stream, a, b, members_a);
+  MB_LAUNCH_OK("k_mlp3_fwd2");
+  return 0;
+}
+
+static int narrow_tiles(int Np3) { return Np3 == 16 ? 1 : Np3 == 32 ? 2 : 0; }
+
+// ReLU nets a and b in one launch (either may be empty)
+int launch_mlp3_fwd_pair(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, hipStream_t stream) {
+  if (a.rows <= 0) return launch_mlp3_fwd(b, members_b, ACT_RELU, stream);
+  if (b.rows <= 0) return launch_mlp3_fwd(a, members_a, ACT_RELU, stream);
+  static const bool split = [] { const char* e = getenv("MOBODY_NO_FWD_PAIR"); return e && atoi(e) != 0; }();   // tuning aid
+  if (split || a.Np3 != b.Np3) {                  // the merged kernel is specialised on one output-layer width
+    int rc = launch_mlp3_fwd(a, members_a, ACT_RELU, stream);
+    return rc ? rc : launch_mlp3_fwd(b, members_b, ACT_RELU, stream);
+  }
+  const bool tall = pick_tile_rows(a.rows, members_a) == 64;
+  const int nt = narrow_tiles(a.Np3);
+  if (tall) return nt == 1 ? launch_fwd2_t<2, 1>(a, members_a, b, members_b, stream)
+                 : nt == 2 ? launch_fwd2_t<2, 2>(a, members_a, b, members_b, stream)
+                           : launch_fwd2_t<2, 0>(a, members_a, b, members_b, stream);
+  return nt == 1 ? launch_fwd2_t<1, 1>(a, members_a, b, members_b, stream)
+       : nt == 2 ? launch_fwd2_t<1, 2>(a, members_a, b, members_b, stream)
+                 : launch_fwd2_t<1, 0>(a, members_a, b, members_b, stream);
+}
+
+template <int ACT>
+static int launch_fwd_act(const Mlp3FwdArgs& a, int members, hipStream_t stream) {
+  static const int shape = [] { const char* e = getenv("MOBODY_FWD_SHAPE"); return e ? atoi(e) : 0; }();   // tuning aid
+  if (shape == 8) return launch_fwd_t<ACT, 1, 2, 0>(a, members, stream);
+  const bool tall = pick_tile_rows(a.rows, members) == 64;
+  const int nt = narrow_tiles(a.Np3);
+  if (tall) return nt == 1 ? launch_fwd_t<ACT, 2, 1, 1>(a, members, stream)
+                 : nt == 2 ? launch_fwd_t<ACT, 2, 1, 2>(a, members, stream)
+                           : launch_fwd_t<ACT, 2, 1, 0>(a, members, stream);
+  return nt == 1 ? launch_fwd_t<ACT, 1, 1, 1>(a, members, stream)
+       : nt == 2 ? launch_fwd_t<ACT, 1, 1, 2>(a, members, stream)
+                 : launch_fwd_t<ACT, 1, 1, 0>(a, members, stream);
+}
+
 int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stream) {
   if (a.rows <= 0) return 0;
-  static const int shape = [] { const char* e = getenv("MOBODY_FWD_SHAPE"); return e ? atoi(e) : 0; }();   // tuning aid
-  const bool tall = pick_tile_rows(a.rows, members) == 64;
-  if (act == ACT_SWISH) {
-    if (shape == 8) return launch_fwd_t<ACT_SWISH, 1, 2>(a, members, stream);
-    return tall ? launch_fwd_t<ACT_SWISH, 2, 1>(a, members, stream) : launch_fwd_t<ACT_SWISH, 1, 1>(a, members, stream);
-  }
-  if (shape == 8) return launch_fwd_t<ACT_RELU, 1, 2>(a, members, stream);
-  return tall ? launch_fwd_t<ACT_RELU, 2, 1>(a, members, stream) : launch_fwd_t<ACT_RELU, 1, 1>(a, members, stream);
+  return act == ACT_SWISH ? launch_fwd_act<ACT_SWISH>(a, members, stream) : launch_fwd_act<ACT_RELU>(a, members, stream);
 }
 
 }  // namespace mobody

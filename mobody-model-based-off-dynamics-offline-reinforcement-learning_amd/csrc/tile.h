@@ -78,26 +78,45 @@ __device__ __forceinline__ void wide_zero(f32x16 (&acc)[MT][2]) {
 // fetches its B fragments for a whole chunk with ONE 16-byte load and a wave instruction reads 1 KB contiguous.
 __host__ __device__ inline long long wide_idx(int k, int n) { return ((long long)(k >> 2) * HID + n) * 4 + (k & 3); }
 
+// Register ring of weight fragments: chunk c of four k-steps is requested WIDE_RING-1 chunks before its MFMAs.
+// One chunk is 8*MT MFMAs = 512*MT cycles of this wave's pipe time, while an L2 round trip under load is
+// ~0.9 us (~2000 cycles): throughput per wave = bytes in flight / latency, so 4 chunks (2 KB per wave) are
+// kept in flight.  (With 2 chunks of 4-byte loads the 640-workgroup twin-Q forward ran at 35 % MFMA busy.)
+constexpr int WIDE_RING = 5;
+struct WideRing { f32x4 r[WIDE_RING][2]; };
+
+__device__ __forceinline__ void wide_ldb(const float* __restrict__ W, int Kp, int c, f32x4 (&b)[2]) {
+  const int lane = lane_id();
+  const int i = lane & 31, h = lane >> 5;
+  const int nch = Kp >> 3;                      // chunks of four k-steps per lane half
+  // per-lane part of the weight address as a 32-bit element offset; the chunk advance is wave-uniform
+  const int lane_off = ((h * nch) * HID + 64 * wave_col() + i) * 4;
+  const float* wn = W + (size_t)c * (HID * 4);
+  b[0] = *reinterpret_cast<const f32x4*>(wn + lane_off);
+  b[1] = *reinterpret_cast<const f32x4*>(wn + lane_off + 128);
+}
+
+// Request the first WIDE_RING-1 chunks of W.  Called as early as the data dependences allow (before the input
+// tile is in LDS, before the previous layer's epilogue): a layer that starts with a cold ring puts one L2/HBM round
+// trip (~1 us) in front of its first MFMA, and in a single-generation launch every workgroup does so at once.
+__device__ __forceinline__ void wide_prefetch(const float* __restrict__ W, int Kp, WideRing& ring) {
+  const int nch = Kp >> 3;
+#pragma unroll
+  for (int j = 0; j < WIDE_RING - 1; ++j)
+    if (j < nch) wide_ldb(W, Kp, j, ring.r[j]);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// `ring` must hold wide_prefetch(W, Kp).
 template <int MT>
 __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const float* __restrict__ W, int Kp,
-                                          f32x16 (&acc)[MT][2]) {
-  constexpr int R = 5;                          // register ring: weight fragments are requested R-1 = 4 chunks ahead
-  const int lane = lane_id(), w = wave_col();
+                                          f32x16 (&acc)[MT][2], WideRing& ring) {
+  constexpr int R = WIDE_RING;
+  const int lane = lane_id();
   const int i = lane & 31, h = lane >> 5;
   const int kh = Kp >> 1;                       // K range of this lane half, multiple of 4
   const int nch = kh >> 2;                      // chunks of four k-steps
   const float* xa = Xs + (32 * MT * wave_rg() + i) * LDX + h * kh;
-  // per-lane part of the weight address as a 32-bit element offset; the chunk advance is wave-uniform, so the loads
-  // can use the scalar-base + vector-offset form instead of 64-bit vector adds in the unrolled loop
-  const int lane_off = ((h * nch) * HID + 64 * w + i) * 4;
-  // One chunk is 8*MT MFMAs = 512*MT cycles of this wave's pipe time, while an L2 round trip under load is
-  // ~0.9 us (~2000 cycles): throughput per wave = bytes in flight / latency, so 4 chunks (2 KB per wave) are
-  // kept in flight.  (With 2 chunks of 4-byte loads the 640-workgroup twin-Q forward ran at 35 % MFMA busy.)
-  auto ldb = [&](int c, f32x4 (&b)[2]) {
-    const float* wn = W + (size_t)c * (HID * 4);
-    b[0] = *reinterpret_cast<const f32x4*>(wn + lane_off);
-    b[1] = *reinterpret_cast<const f32x4*>(wn + lane_off + 128);
-  };
   auto mma = [&](int c, f32x4 (&b)[2]) {
     f32x4 av[MT];
 #pragma unroll
@@ -112,25 +131,29 @@ __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const fl
       }
     __builtin_amdgcn_s_setprio(0);
   };
-  f32x4 ring[R][2];
-#pragma unroll
-  for (int j = 0; j < R - 1; ++j)
-    if (j < nch) ldb(j, ring[j]);
   for (int c0 = 0; c0 < nch; c0 += R) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const int c = c0 + j;
       if (c < nch) {
-        if (c + R - 1 < nch) ldb(c + R - 1, ring[(j + R - 1) % R]);
+        if (c + R - 1 < nch) wide_ldb(W, Kp, c + R - 1, ring.r[(j + R - 1) % R]);
         // Pin the issue order: without this fence hipcc sinks each prefetch load down to its first use (it trades
         // the ring's registers for occupancy), which collapses the 4-chunk prefetch distance to ~1 chunk and puts
         // an L2 round trip in front of every chunk's MFMAs (seen in the ISA: load ... vmcnt(1) ... mfma of it).
         __builtin_amdgcn_sched_barrier(0);
-        mma(c, ring[j]);
+        mma(c, ring.r[j]);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+}
+
+template <int MT>
+__device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const float* __restrict__ W, int Kp,
+                                          f32x16 (&acc)[MT][2]) {
+  WideRing ring;
+  wide_prefetch(W, Kp, ring);
+  wide_gemm<MT>(Xs, W, Kp, acc, ring);
 }
 
 // Visit every accumulator element of a wide result: f(row 0..32*MT-1, col 0..255, value).
@@ -239,6 +262,69 @@ __device__ __forceinline__ void narrow_layer(const float* __restrict__ Xs, const
     narrow_gemm<1>(Xs, W, Kp, Np, nt0, acc, bm);
 #pragma unroll
     for (int r = 0; r < 4; ++r) f(16 * w + 4 * q + r, 16 * nt0 + i, acc[0][r]);
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// K-split narrow layer (K = 256, Np = 16*NT <= 32, 4 waves, rows = 16*MTN): wave w contracts k in [64w, 64w+64)
+// for ALL rows, so its weight fragments are just 16*NT registers that can be requested long before the layer
+// starts (narrow_prefetch); the four partial results meet in LDS.  The row-split narrow_gemm above keeps two of
+// four waves idle on a 32-row tile and walks K = 256 in four dependent load rounds (3.7 us per tile measured,
+// against 0.2 us of MFMA work).  Lane (i = lane&15, q = lane>>4) supplies k = 64w + 16q + s at step s.
+// --------------------------------------------------------------------------------------------
+template <int NT>
+struct NarrowRegs { float b[16][NT]; };
+
+template <int NT>
+__device__ __forceinline__ void narrow_prefetch(const float* __restrict__ W, int Np, NarrowRegs<NT>& br) {
+  const int lane = lane_id();
+  const float* wb = W + (size_t)(64 * wave_id() + 16 * (lane >> 4)) * Np + (lane & 15);
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) br.b[s][n] = wb[(size_t)s * Np + 16 * n];
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// f(row, col, value) is called once per output element (row < 16*MTN, col < 16*NT).  Overwrites Xs.
+template <int MTN, int NT, class F>
+__device__ __forceinline__ void narrow_run(float* Xs, const NarrowRegs<NT>& br, F&& f) {
+  constexpr int Np = 16 * NT, ROWS = 16 * MTN;
+  const int lane = lane_id(), w = wave_id();
+  const int i = lane & 15, q = lane >> 4;
+  f32x4 acc[MTN][NT];
+#pragma unroll
+  for (int m = 0; m < MTN; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.f;
+  const float* xa = Xs + i * LDX + 64 * w + 16 * q;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    f32x4 av[MTN];
+#pragma unroll
+    for (int m = 0; m < MTN; ++m) av[m] = *reinterpret_cast<const f32x4*>(xa + 16 * m * LDX + 4 * s4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int m = 0; m < MTN; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][u], br.b[4 * s4 + u][n], acc[m][n], 0, 0, 0);
+  }
+  lds_barrier();                                 // every wave has read its slice of the image
+  float* P = Xs + w * (ROWS * Np);
+#pragma unroll
+  for (int m = 0; m < MTN; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(16 * m + 4 * q + r) * Np + 16 * n + i] = acc[m][n][r];
+  lds_barrier();
+  for (int e = threadIdx.x; e < ROWS * Np; e += NTHREADS) {
+    const float v = ((Xs[e] + Xs[ROWS * Np + e]) + Xs[2 * ROWS * Np + e]) + Xs[3 * ROWS * Np + e];
+    f(e / Np, e % Np, v);
   }
 }
 

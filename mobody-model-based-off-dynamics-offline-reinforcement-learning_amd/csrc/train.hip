@@ -285,15 +285,15 @@ extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h
   hipStream_t st = as_stream(stream);
   const long long N = d->N;
   const int S = d->S, A = d->A;
-  // online twin-Q(s, a), activations kept for the backward (:196)
-  rc = launch_mlp3_fwd(fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q), 2, ACT_RELU, st);
-  if (rc) return rc;
+  // online twin-Q(s, a), activations kept for the backward (:196), together with a' = pi(s') (:191) in one launch
+  const Mlp3FwdArgs fq = fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q);
   if (q_next == nullptr) {
-    // a' = pi(s')                                                             (mobody.py:191)
-    rc = launch_mlp3_fwd(fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pi, 1, h->max_action, nullptr, nullptr, nullptr), 1, ACT_RELU, st);
+    rc = launch_mlp3_fwd_pair(fq, 2, fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pi, 1, h->max_action, nullptr, nullptr, nullptr), 1, st);
     // target twin-Q(s', a')                                                    (:192)
     if (!rc) rc = launch_mlp3_fwd(fwd_args(qtarg_blob, w.Lq, next_state, S, w.pi, A, N, w.qt, 0, 1.f, nullptr, nullptr, nullptr), 2, ACT_RELU, st);
-  }   // else: q_next = V(s') supplied by the caller (update_q_functions_1, :210-229)
+  } else {
+    rc = launch_mlp3_fwd(fq, 2, ACT_RELU, st);     // q_next = V(s') supplied by the caller (update_q_functions_1, :210-229)
+  }
   if (rc) return rc;
   const float invNg = 1.f / (float)d->N_global;
   // TD error -> dz3 in the backward's prologue (mobody.py:190-207), then dz2, dz1 and the bias partials
@@ -319,11 +319,10 @@ extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper*
   hipStream_t st = as_stream(stream);
   const long long N = d->N, Nt = d->Nt;
   const int S = d->S, A = d->A;
-  // Q(s_true, a_true) for the BC weights (:251)
-  rc = launch_mlp3_fwd(fwd_args(q_blob, w.Lq, state, S, action, A, Nt, w.qb, 0, 1.f, nullptr, nullptr, nullptr), 2, ACT_RELU, st);
-  if (rc) return rc;
-  // pi(s) on the whole mixed batch (its first Nt rows are pi(s_true), mobody.py:249,315)
-  rc = launch_mlp3_fwd(fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a), 1, ACT_RELU, st);
+  // Q(s_true, a_true) for the BC weights (:251) and pi(s) on the whole mixed batch (its first Nt rows are
+  // pi(s_true), mobody.py:249,315) in one launch
+  rc = launch_mlp3_fwd_pair(fwd_args(q_blob, w.Lq, state, S, action, A, Nt, w.qb, 0, 1.f, nullptr, nullptr, nullptr), 2,
+                            fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a), 1, st);
   // Q(s, pi(s)) with the freshly updated critic, activations kept for dQ/da   (:316)
   if (!rc) rc = launch_mlp3_fwd(fwd_args(q_blob, w.Lq, state, S, w.pi, A, N, w.q, 0, 1.f, nullptr, w.h1q, w.h2q), 2, ACT_RELU, st);
   if (rc) return rc;
