@@ -9,6 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libmobody_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
+if os.environ.get("MOBODY_TRACE") == "1":          # diagnostic build: phase timestamps in the MLP kernels (needs -fgpu-rdc
+    FLAGS += ["-DMOBODY_TRACE", "-fgpu-rdc"]       # for the one trace buffer shared by the translation units)
 
 
 def _stale(target, deps):
@@ -38,7 +40,7 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *(["-fgpu-rdc"] if "-fgpu-rdc" in FLAGS else []), "-o", LIB, *objs])
     return LIB
 
 

@@ -61,4 +61,18 @@ inline MlpView mlp_view(const float* blob, const MobodyMlpLayout& L) {
   return v;
 }
 
+// Phase timeline of the fused MLP kernels (diagnostic builds only: MOBODY_TRACE=1 python build.py --force).
+// TR(k) stores the 100 MHz wall clock of workgroup (blockIdx.y, blockIdx.x) at phase k; tools/trace_mlp.py reads it.
+#ifdef MOBODY_TRACE
+constexpr int TRACE_BLOCKS = 16384, TRACE_SLOTS = 8;
+extern __device__ unsigned long long g_trace[TRACE_BLOCKS * TRACE_SLOTS];
+#define TR(k)                                                                                                     \
+  do {                                                                                                            \
+    if (threadIdx.x == 0)                                                                                         \
+      g_trace[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) % TRACE_BLOCKS) * TRACE_SLOTS + (k)] = wall_clock64(); \
+  } while (0)
+#else
+#define TR(k)
+#endif
+
 }  // namespace mobody

@@ -44,6 +44,13 @@ ProfScope::~ProfScope() {
 
 using namespace mobody;
 
+#ifdef MOBODY_TRACE
+namespace mobody { __device__ unsigned long long g_trace[TRACE_BLOCKS * TRACE_SLOTS]; }
+extern "C" int mobody_debug_trace(unsigned long long* host_out, int n) {      // diagnostic builds only, not in the header
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mobody::g_trace), sizeof(unsigned long long) * n);
+}
+#endif
+
 extern "C" int mobody_prof_begin(int max_events) {
   MB_REQUIRE(max_events > 0 && max_events <= (1 << 20), "mobody_prof_begin: bad capacity");
   auto& p = prof_pool();

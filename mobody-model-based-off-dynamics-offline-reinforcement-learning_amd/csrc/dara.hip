@@ -138,7 +138,7 @@ static void carve_bwd(const MobodyMlpLayout& L, long long rows, float* base, Bwd
   w.dz1 = take((long long)L.members * rows * HID);
   w.tile_rows = pick_tile_rows(rows, L.members);
   w.ntiles = (int)cdiv(rows, w.tile_rows);
-  w.nsplit = wgrad_nsplit(rows);
+  w.nsplit = wgrad_nsplit(rows, L.members);
   w.dbp = take((long long)w.ntiles * L.members * (2 * HID + L.Np3));
   w.slab_stride = (L.total_floats + 3) & ~3LL;
   w.slabs = take(w.slab_stride * w.nsplit);

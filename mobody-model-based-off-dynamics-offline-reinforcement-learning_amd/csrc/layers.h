@@ -22,6 +22,7 @@ __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ 
   f32x16 acc[MT][2];
   wide_zero<MT>(acc);
   wide_gemm<MT>(Xs, W, Kp, acc, ring);
+  if (Kp == HID) TR(3);
   between();
   lds_barrier();                         // every wave has finished reading the old image
   wide_foreach<MT>(acc, [&](int row, int col, float v) {

@@ -136,7 +136,7 @@ __device__ __forceinline__ void bwd_seed(const Mlp3BwdArgs& a, float* Xs, float*
 // NT (DX only): 16-column tiles of the input-gradient layer handled by the K-split narrow layer (Np1t == 16*NT),
 // or 0 = any Np1t through the row-split path.
 template <bool DX, int MT, int NT>
-__global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
+__global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   __shared__ float red[8];
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   constexpr int TB = 32 * MT;
@@ -153,11 +153,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   float* dz1 = a.dz1 ? a.dz1 + ((long long)m * a.rows + row0) * HID : nullptr;
   float* dbp = a.dbp + ((long long)blockIdx.x * gridDim.y + m) * (2 * HID + a.Np3);
 
+  TR(0);
   WideRing ring;
   wide_prefetch(w3t, a.Np3, ring);                // weight fragments travel while the seed rows are fetched
   if (a.seed.mode == 0) tile_load(Xs, 0, a.dz3 + ((long long)m * a.rows + row0) * a.Np3, a.Np3, a.Np3, 0, rows_here, TB);
   else bwd_seed(a, Xs, red, m, row0, rows_here, TB);
   lds_barrier();
+  TR(1);
   if ((int)threadIdx.x < a.Np3) {                 // db3 partial of this tile
     float s = 0.f;
     for (int r = 0; r < TB; ++r) s += Xs[r * LDX + threadIdx.x];
@@ -169,19 +171,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   // dh2 = dz3 * W3^T ; dz2 = dh2 * [h2 > 0]
   wide_zero<MT>(acc);
   wide_gemm<MT>(Xs, w3t, a.Np3, acc, ring);
+  TR(2);
   wide_prefetch(w2t, HID, ring);                  // next layer's first fragments overlap the mask epilogue
   lds_barrier();
   wide_mask_store_colsum<MT>(acc, Xs, h2, dz2, rows_here, cs);
   if (lane < 32) { dbp[HID + 64 * w + lane] = cs[0]; dbp[HID + 64 * w + 32 + lane] = cs[1]; }
   lds_barrier();
+  TR(3);
   // dh1 = dz2 * W2^T ; dz1 = dh1 * [h1 > 0]
   wide_zero<MT>(acc);
   wide_gemm<MT>(Xs, w2t, HID, acc, ring);
+  TR(4);
   NarrowRegs<(NT > 0 ? NT : 1)> br;
   if constexpr (DX && NT > 0) narrow_prefetch<NT>(w1t, 16 * NT, br);
   lds_barrier();
   wide_mask_store_colsum<MT>(acc, Xs, h1, dz1, rows_here, cs);
   if (lane < 32) { dbp[64 * w + lane] = cs[0]; dbp[64 * w + 32 + lane] = cs[1]; }
+  TR(5);
   if constexpr (DX) {
     lds_barrier();
     float* dx = a.dx + ((long long)m * a.rows + row0) * a.dx_n;
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
     if constexpr (NT > 0) narrow_run<TB / 16, NT>(Xs, br, emit);
     else narrow_layer(Xs, w1t, HID, a.Np1t, emit, TB);
   }
+  TR(6);
 }
 
 template <bool DX, int MT, int NT>
@@ -303,21 +310,29 @@ __device__ __forceinline__ void wgrad_tile(const WgradJob& jb, const WgradArgs& 
   }
 
   // ---- reduce the four row slices of this workgroup through LDS, write one slab tile ----
-  float* mine = red + w * (TK * TN);
+  // Two tile buffers (32 KB), not four: waves 0,1 store, waves 2,3 add onto them (same lane <-> element map, so no
+  // conflicts).  With four buffers (64 KB) only two workgroups fit a CU and a 768-workgroup launch needs two rounds.
+  float* mine = red + (w & 1) * (TK * TN);
+  auto sweep = [&](bool add) {
 #pragma unroll
-  for (int x = 0; x < MT; ++x)
+    for (int x = 0; x < MT; ++x)
 #pragma unroll
-    for (int y = 0; y < NT; ++y)
+      for (int y = 0; y < NT; ++y)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kk = 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
-        mine[kk * TN + 32 * y + i] = acc[x][y][r];
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int kk = 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float* p = mine + kk * TN + 32 * y + i;
+          *p = add ? *p + acc[x][y][r] : acc[x][y][r];
+        }
+  };
+  if (w < 2) sweep(false);
+  __syncthreads();
+  if (w >= 2) sweep(true);
   __syncthreads();
   float* slab = a.slabs + (long long)slice * a.slab_stride + jb.out_off + m * a.out_mstride;
   for (int idx = threadIdx.x; idx < TK * TN; idx += NTHREADS) {
     const int kk = idx / TN, nn = idx - kk * TN;
-    const float s = (red[idx] + red[TK * TN + idx]) + (red[2 * TK * TN + idx] + red[3 * TK * TN + idx]);
+    const float s = red[idx] + red[TK * TN + idx];
     const int gk = k0 + kk, gn = n0 + nn;
     if (gk < jb.out_k && gn < jb.out_n) {
       if (jb.transposed) slab[(long long)gn * jb.out_ld + gk] = s;
@@ -327,8 +342,8 @@ __device__ __forceinline__ void wgrad_tile(const WgradJob& jb, const WgradArgs& 
   }
 }
 
-__global__ __launch_bounds__(NTHREADS, 2) void k_wgrad(WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float red[];     // [4 waves][64][64]
+__global__ __launch_bounds__(NTHREADS, 4) void k_wgrad(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];     // [2][64][64]
   // XCD-aware decode: blocks with equal (id % 8) share an XCD; consecutive ones walk the tiles of one (slice, member)
   const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
   const int sm = xcd + 8 * (j / a.tiles_total);
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_wgrad(WgradArgs a) {
 
 int launch_wgrad(WgradArgs a, hipStream_t st) {
   if (a.rows <= 0) return 0;
-  constexpr size_t lds = (size_t)4 * 64 * 64 * sizeof(float);
+  constexpr size_t lds = (size_t)2 * 64 * 64 * sizeof(float);
   static bool once = false;
   if (!once) {
     int rc = allow_big_lds(k_wgrad, lds);

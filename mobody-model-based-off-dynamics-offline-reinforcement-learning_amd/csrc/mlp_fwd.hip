@@ -37,9 +37,11 @@ __device__ __forceinline__ void mlp3_fwd_tail(const Mlp3FwdArgs& a, int m, float
       narrow_prefetch<NT>(w3, 16 * NT, br);
       bias = b3[mycol < a.nout ? mycol : 0];
     });
+    TR(4);
     narrow_run<TB / 16, NT>(Xs, br, [&](int row, int col, float v) { emit(row, col, v, bias); });
   } else {
     wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [] {});
+    TR(4);
     narrow_layer(Xs, w3, HID, a.Np3, [&](int row, int col, float v) { emit(row, col, v, b3[col < a.nout ? col : 0]); }, TB);
   }
 }
@@ -52,6 +54,7 @@ __device__ __forceinline__ void mlp3_fwd_tile(const Mlp3FwdArgs& a, int m, float
   const int rows_here = (int)min((long long)TB, a.rows - row0);
   const float* w1 = a.w1 + m * a.sw1;
   const float* w2 = a.w2 + m * a.sw2;
+  TR(0);
   WideRing ring;
   wide_prefetch(w1, a.Kp1, ring);                 // W1 fragments travel while the input tile is fetched
 
@@ -66,6 +69,7 @@ __device__ __forceinline__ void mlp3_fwd_tile(const Mlp3FwdArgs& a, int m, float
   }
   tile_zero_cols(Xs, c0, a.Kp1, TB);
   lds_barrier();
+  TR(1);
   if (a.save_x != nullptr && m == 0) {
     for (int idx = threadIdx.x; idx < rows_here * a.Kp1; idx += NTHREADS * RG) {
       const int r = idx / a.Kp1, c = idx - r * a.Kp1;
@@ -78,7 +82,9 @@ __device__ __forceinline__ void mlp3_fwd_tile(const Mlp3FwdArgs& a, int m, float
   wide_layer<ACT, MT>(Xs, w1, a.b1 + m * a.sb1, a.Kp1, ring,
                       [=](int row, int col, float y) { if (h1 != nullptr && row < rows_here) h1[row * HID + col] = y; },
                       [&] { wide_prefetch(w2, HID, ring); });
+  TR(2);
   mlp3_fwd_tail<ACT, MT, RG, NT>(a, m, Xs, ring, h2, row0, rows_here);
+  TR(5);
 }
 
 template <int ACT, int MT, int RG, int NT>

@@ -95,11 +95,13 @@ struct GradReduceArgs {
 };
 int launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);
 
-// split-K factor (workgroups along the row dimension) used for a batch of `rows`
-inline int wgrad_nsplit(long long rows) {
-  long long s = rows / 256;
+// split-K factor (workgroups along the row dimension) used for a batch of `rows`: 24 output tiles x nsplit x members
+// workgroups should reach ~3 per CU (768), so a one-member net splits twice as fine as a twin net
+inline int wgrad_nsplit(long long rows, int members) {
+  const int cap = members == 1 ? 32 : 16;
+  long long s = rows / (members == 1 ? 128 : 256);
   if (s < 1) s = 1;
-  if (s > 16) s = 16;
+  if (s > cap) s = cap;
   return (int)s;
 }
 

@@ -18,8 +18,8 @@ namespace mobody {
 // ------------------------------------------------------------------------------------------------
 struct TrainWs {
   float *pi, *qt, *q, *qb, *xq, *h1q, *h2q, *xa, *h1a, *h2a, *dz3q, *dz2, *dz1, *dz3a, *dxa, *bcw, *dbp, *slabs, *lossp;
-  long long slab_stride, total;
-  int nsplit, ntiles, tile_rows;
+  long long total;
+  int nsplit_q, nsplit_a, ntiles, tile_rows;
   MobodyMlpLayout Lq, La;
 };
 
@@ -50,12 +50,14 @@ static int carve(const MobodyTrainDims& d, float* base, TrainWs& w) {
   w.lossp = take(2 * cdiv(N, 32));                // per (row tile, member) / per-tile pairs, tiles of >= 32 rows
   w.tile_rows = pick_tile_rows(N, 1);             // one value for both nets: the bias partials are per row tile
   w.ntiles = (int)cdiv(N, w.tile_rows);
-  w.nsplit = wgrad_nsplit(N);
+  w.nsplit_q = wgrad_nsplit(N, 2);
+  w.nsplit_a = wgrad_nsplit(N, 1);
   const long long per_q = 2 * HID + w.Lq.Np3, per_a = 2 * HID + w.La.Np3;
   w.dbp = take((long long)w.ntiles * (2 * per_q > per_a ? 2 * per_q : per_a));
-  w.slab_stride = w.Lq.total_floats > w.La.total_floats ? w.Lq.total_floats : w.La.total_floats;
-  w.slab_stride = (w.slab_stride + 3) & ~3LL;
-  w.slabs = take(w.slab_stride * w.nsplit);
+  {                                               // one slab area, used by the critic's and then the actor's gradients
+    const long long sq = ((w.Lq.total_floats + 3) & ~3LL) * w.nsplit_q, sa = ((w.La.total_floats + 3) & ~3LL) * w.nsplit_a;
+    w.slabs = take(sq > sa ? sq : sa);
+  }
   w.total = off;
   return 0;
 }
@@ -234,8 +236,10 @@ static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h
                         const float* dz2, const float* dz1, long long rows, const TrainWs& w, float* grad,
                         const LossFinal& loss, hipStream_t st) {
   WgradArgs g{};
-  g.rows = rows; g.slabs = w.slabs; g.slab_stride = w.slab_stride; g.out_mstride = L.member_floats;
-  g.nsplit = w.nsplit; g.members = L.members;
+  const int nsplit = L.members == 1 ? w.nsplit_a : w.nsplit_q;
+  const long long slab_stride = (L.total_floats + 3) & ~3LL;
+  g.rows = rows; g.slabs = w.slabs; g.slab_stride = slab_stride; g.out_mstride = L.member_floats;
+  g.nsplit = nsplit; g.members = L.members;
   const long long hs = rows * HID;
   // dW2 = h1^T dz2
   g.job[0] = WgradJob{h1, hs, HID, HID, dz2, hs, HID, HID, L.w2, HID, HID, HID, 0, 1, 0, 0};
@@ -245,7 +249,7 @@ static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h
   g.job[2] = WgradJob{dz3, rows * L.Np3, L.Np3, L.Np3, h2, hs, HID, HID, L.w3, L.Np3, L.Np3, HID, 1, 0, 0, 0};
   int rc = launch_wgrad(g, st);
   if (rc) return rc;
-  GradReduceArgs r{L, w.slabs, w.slab_stride, w.nsplit, w.dbp, w.ntiles, grad, loss};
+  GradReduceArgs r{L, w.slabs, slab_stride, nsplit, w.dbp, w.ntiles, grad, loss};
   return launch_grad_reduce(r, st);
 }
 
