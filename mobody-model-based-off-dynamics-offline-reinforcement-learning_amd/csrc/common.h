@@ -46,7 +46,7 @@ struct ProfScope {
 
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
-inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // device-side view of one packed MLP (member 0 pointers + strides), built from MobodyMlpLayout
 struct MlpView {

@@ -4,6 +4,7 @@
 //   the ensemble reward head               (Swish; mobody_module.py:295-302)
 //   the DARA classifier heads              (ReLU;  mobody.py:11-33)
 #pragma once
+#include <stdint.h>
 #include <stdlib.h>
 
 #include "tile.h"
@@ -14,9 +15,11 @@ namespace mobody {
 // `ring` holds wide_prefetch(W, Kp); `between()` runs after the last MFMA and before the epilogue -- the place to
 // request the NEXT layer's first weight fragments (the ring's registers are free again), so their L2/HBM round trip
 // overlaps this layer's barrier + epilogue instead of stalling the next GEMM.
+// `mask` (optional): this tile's [MT][256] words; bit r of word (mt, col) = [y(row 32 mt + r, col) > 0].  The backward
+// pass of a ReLU net needs only these signs, 32 B per row instead of the 1 KB activation row.
 template <int ACT, int MT = 2, class Extra, class Between>
 __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ W, const float* __restrict__ b, int Kp,
-                                           WideRing& ring, Extra&& extra, Between&& between) {
+                                           WideRing& ring, Extra&& extra, Between&& between, uint32_t* mask = nullptr) {
   // the wave's two bias values (columns 64w + 32nt + lane&31): requested before the GEMM, consumed after it
   const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
   f32x16 acc[MT][2];
@@ -30,6 +33,21 @@ __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ 
     Xs[row * LDX + col] = y;
     extra(row, col, y);
   });
+  if (mask != nullptr) {
+    const int i = lane_id() & 31, hh = lane_id() >> 5;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const float bias = nt ? bias1 : bias0;
+        uint32_t word = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          word |= (uint32_t)(activate<ACT>(acc[mt][nt][r] + bias) > 0.f) << ((r & 3) + 8 * (r >> 2) + 4 * hh);
+        word |= (uint32_t)__shfl_xor((int)word, 32);        // the other lane half holds the other 16 rows
+        if (hh == 0) mask[(32 * MT * wave_rg() / 32 + mt) * HID + 64 * wave_col() + 32 * nt + i] = word;
+      }
+  }
   lds_barrier();
 }
 
@@ -58,6 +76,8 @@ struct Mlp3FwdArgs {
   float* save_x;            // [rows][Kp1]           (optional, written by member 0)
   float* save_h1;           // [members][rows][256]  (optional)
   float* save_h2;
+  uint32_t* mask1;          // [members][ceil(rows/32)][256] sign bits of h1 / h2 (optional, see wide_layer)
+  uint32_t* mask2;
   int out_mode;             // 0 raw, 1 max_action*tanh
   float max_action;
 };

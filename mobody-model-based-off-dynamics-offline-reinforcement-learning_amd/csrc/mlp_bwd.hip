@@ -25,21 +25,28 @@ namespace mobody {
 // round trips per layer, measured 60 % SQ_WAIT_ANY) -- so all 64 are in flight together and cost one round trip.
 // (Holding them across the GEMM instead was tried: 256 VGPRs + 62 spills, slower.)
 // Lanes < 32 end up with the 64-row sums of columns 64w + 32nt + (lane&31), nt = 0,1.
-template <int MT>
+template <int MT, bool BITS>
 __device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], float* Xs, const float* __restrict__ h,
-                                                       float* gdst, int rows_here, float (&cs)[2]) {
+                                                       const uint32_t* __restrict__ bits, float* gdst, int rows_here,
+                                                       float (&cs)[2]) {
   const int lane = lane_id(), w = wave_id();
   const int i = lane & 31, hh = lane >> 5;
-  const float* hp = h + 64 * w + i;
-  float hv[MT][2][16];
+  float hv[BITS ? 1 : MT][2][BITS ? 1 : 16];
+  uint32_t mw[MT][2];
+  if constexpr (BITS) {                            // two words per 32-row tile and lane instead of 32 activations
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) { mw[mt][0] = bits[mt * HID + 64 * w + i]; mw[mt][1] = bits[mt * HID + 64 * w + 32 + i]; }
+  } else {
+    const float* hp = h + 64 * w + i;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = min(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh, rows_here - 1);
-      hv[mt][0][r] = hp[row * HID];
-      hv[mt][1][r] = hp[row * HID + 32];
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh, rows_here - 1);
+        hv[mt][0][r] = hp[row * HID];
+        hv[mt][1][r] = hp[row * HID + 32];
+      }
+  }
   cs[0] = cs[1] = 0.f;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -47,9 +54,13 @@ __device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], flo
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int rb = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int row = 32 * mt + rb;
         const int col = 64 * w + 32 * nt + i;
-        const float dz = (hv[mt][nt][r] > 0.f && row < rows_here) ? acc[mt][nt][r] : 0.f;
+        bool on;
+        if constexpr (BITS) on = (mw[mt][nt] >> rb) & 1u;
+        else on = hv[mt][nt][r] > 0.f;
+        const float dz = (on && row < rows_here) ? acc[mt][nt][r] : 0.f;
         Xs[row * LDX + col] = dz;
         if (gdst != nullptr && row < rows_here) gdst[row * HID + col] = dz;
         cs[nt] += dz;
@@ -135,7 +146,8 @@ __device__ __forceinline__ void bwd_seed(const Mlp3BwdArgs& a, float* Xs, float*
 
 // NT (DX only): 16-column tiles of the input-gradient layer handled by the K-split narrow layer (Np1t == 16*NT),
 // or 0 = any Np1t through the row-split path.
-template <bool DX, int MT, int NT>
+// BITS: ReLU masks come from the forward's sign words (m1, m2) instead of the saved activations (h1, h2).
+template <bool DX, int MT, int NT, bool BITS>
 __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   __shared__ float red[8];
   extern __shared__ __attribute__((aligned(16))) float Xs[];
@@ -147,8 +159,11 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdA
   const float* w3t = a.wt + m * a.t_mstride + a.w3t;
   const float* w2t = a.wt + m * a.t_mstride + a.w2t;
   const float* w1t = a.wt + m * a.t_mstride + a.w1t;
-  const float* h1 = a.h1 + ((long long)m * a.rows + row0) * HID;
-  const float* h2 = a.h2 + ((long long)m * a.rows + row0) * HID;
+  const float* h1 = BITS ? nullptr : a.h1 + ((long long)m * a.rows + row0) * HID;
+  const float* h2 = BITS ? nullptr : a.h2 + ((long long)m * a.rows + row0) * HID;
+  const long long mtile = ((long long)m * cdiv(a.rows, 32) + row0 / 32) * HID;
+  const uint32_t* m1 = BITS ? a.m1 + mtile : nullptr;
+  const uint32_t* m2 = BITS ? a.m2 + mtile : nullptr;
   float* dz2 = a.dz2 ? a.dz2 + ((long long)m * a.rows + row0) * HID : nullptr;
   float* dz1 = a.dz1 ? a.dz1 + ((long long)m * a.rows + row0) * HID : nullptr;
   float* dbp = a.dbp + ((long long)blockIdx.x * gridDim.y + m) * (2 * HID + a.Np3);
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdA
   TR(2);
   wide_prefetch(w2t, HID, ring);                  // next layer's first fragments overlap the mask epilogue
   lds_barrier();
-  wide_mask_store_colsum<MT>(acc, Xs, h2, dz2, rows_here, cs);
+  wide_mask_store_colsum<MT, BITS>(acc, Xs, h2, m2, dz2, rows_here, cs);
   if (lane < 32) { dbp[HID + 64 * w + lane] = cs[0]; dbp[HID + 64 * w + 32 + lane] = cs[1]; }
   lds_barrier();
   TR(3);
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdA
   NarrowRegs<(NT > 0 ? NT : 1)> br;
   if constexpr (DX && NT > 0) narrow_prefetch<NT>(w1t, 16 * NT, br);
   lds_barrier();
-  wide_mask_store_colsum<MT>(acc, Xs, h1, dz1, rows_here, cs);
+  wide_mask_store_colsum<MT, BITS>(acc, Xs, h1, m1, dz1, rows_here, cs);
   if (lane < 32) { dbp[64 * w + lane] = cs[0]; dbp[64 * w + 32 + lane] = cs[1]; }
   TR(5);
   if constexpr (DX) {
@@ -201,34 +216,40 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdA
   TR(6);
 }
 
-template <bool DX, int MT, int NT>
+template <bool DX, int MT, int NT, bool BITS>
 static int launch_bwd_t(const Mlp3BwdArgs& a, int members, hipStream_t st) {
   constexpr size_t lds = (size_t)32 * MT * LDX * sizeof(float);
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_mlp3_bwd<DX, MT, NT>, lds);
+    int rc = allow_big_lds(k_mlp3_bwd<DX, MT, NT, BITS>, lds);
     if (rc) return rc;
     once = true;
   }
   dim3 grid((unsigned)cdiv(a.rows, 32 * MT), (unsigned)members);
   ProfScope prof(PROF_MLP_BWD, st);
-  hipLaunchKernelGGL((k_mlp3_bwd<DX, MT, NT>), grid, dim3(NTHREADS), lds, st, a);
+  hipLaunchKernelGGL((k_mlp3_bwd<DX, MT, NT, BITS>), grid, dim3(NTHREADS), lds, st, a);
   MB_LAUNCH_OK("k_mlp3_bwd");
   return 0;
 }
 
 // tile_rows (32 or 64) must be the value the caller sized `dbp` / the bias reduction with
-int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, int tile_rows, hipStream_t st) {
-  if (a.rows <= 0) return 0;
+template <bool BITS>
+static int launch_bwd_masks(const Mlp3BwdArgs& a, int members, bool with_dx, int tile_rows, hipStream_t st) {
   const int nt = a.Np1t == 16 ? 1 : a.Np1t == 32 ? 2 : 0;
   if (tile_rows == 32) {
-    if (!with_dx) return launch_bwd_t<false, 1, 0>(a, members, st);
-    return nt == 1 ? launch_bwd_t<true, 1, 1>(a, members, st) : nt == 2 ? launch_bwd_t<true, 1, 2>(a, members, st)
-                                                                         : launch_bwd_t<true, 1, 0>(a, members, st);
+    if (!with_dx) return launch_bwd_t<false, 1, 0, BITS>(a, members, st);
+    return nt == 1 ? launch_bwd_t<true, 1, 1, BITS>(a, members, st) : nt == 2 ? launch_bwd_t<true, 1, 2, BITS>(a, members, st)
+                                                                               : launch_bwd_t<true, 1, 0, BITS>(a, members, st);
   }
-  if (!with_dx) return launch_bwd_t<false, 2, 0>(a, members, st);
-  return nt == 1 ? launch_bwd_t<true, 2, 1>(a, members, st) : nt == 2 ? launch_bwd_t<true, 2, 2>(a, members, st)
-                                                                       : launch_bwd_t<true, 2, 0>(a, members, st);
+  if (!with_dx) return launch_bwd_t<false, 2, 0, BITS>(a, members, st);
+  return nt == 1 ? launch_bwd_t<true, 2, 1, BITS>(a, members, st) : nt == 2 ? launch_bwd_t<true, 2, 2, BITS>(a, members, st)
+                                                                             : launch_bwd_t<true, 2, 0, BITS>(a, members, st);
+}
+
+int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, int tile_rows, hipStream_t st) {
+  if (a.rows <= 0) return 0;
+  return a.m1 != nullptr && a.m2 != nullptr ? launch_bwd_masks<true>(a, members, with_dx, tile_rows, st)
+                                            : launch_bwd_masks<false>(a, members, with_dx, tile_rows, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ namespace mobody {
 // Output layer of the forward (256 -> nout <= 16*NT) through the K-split narrow layer; NT = 0: generic row-split path.
 template <int ACT, int MT, int RG, int NT>
 __device__ __forceinline__ void mlp3_fwd_tail(const Mlp3FwdArgs& a, int m, float* Xs, WideRing& ring, float* h2,
-                                              long long row0, int rows_here) {
+                                              uint32_t* mask2, long long row0, int rows_here) {
   constexpr int TB = 32 * MT * RG;
   const float* w3 = a.w3 + m * a.sw3;
   const float* b3 = a.b3 + m * a.sb3;
@@ -36,11 +36,11 @@ __device__ __forceinline__ void mlp3_fwd_tail(const Mlp3FwdArgs& a, int m, float
     wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [&] {
       narrow_prefetch<NT>(w3, 16 * NT, br);
       bias = b3[mycol < a.nout ? mycol : 0];
-    });
+    }, mask2);
     TR(4);
     narrow_run<TB / 16, NT>(Xs, br, [&](int row, int col, float v) { emit(row, col, v, bias); });
   } else {
-    wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [] {});
+    wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [] {}, mask2);
     TR(4);
     narrow_layer(Xs, w3, HID, a.Np3, [&](int row, int col, float v) { emit(row, col, v, b3[col < a.nout ? col : 0]); }, TB);
   }
@@ -79,11 +79,14 @@ __device__ __forceinline__ void mlp3_fwd_tile(const Mlp3FwdArgs& a, int m, float
 
   float* h1 = a.save_h1 ? a.save_h1 + ((long long)m * a.rows + row0) * HID : nullptr;
   float* h2 = a.save_h2 ? a.save_h2 + ((long long)m * a.rows + row0) * HID : nullptr;
+  const long long mtile = ((long long)m * cdiv(a.rows, 32) + row0 / 32) * HID;      // this tile's first mask word
+  uint32_t* mask1 = a.mask1 ? a.mask1 + mtile : nullptr;
+  uint32_t* mask2 = a.mask2 ? a.mask2 + mtile : nullptr;
   wide_layer<ACT, MT>(Xs, w1, a.b1 + m * a.sb1, a.Kp1, ring,
                       [=](int row, int col, float y) { if (h1 != nullptr && row < rows_here) h1[row * HID + col] = y; },
-                      [&] { wide_prefetch(w2, HID, ring); });
+                      [&] { wide_prefetch(w2, HID, ring); }, mask1);
   TR(2);
-  mlp3_fwd_tail<ACT, MT, RG, NT>(a, m, Xs, ring, h2, row0, rows_here);
+  mlp3_fwd_tail<ACT, MT, RG, NT>(a, m, Xs, ring, h2, mask2, row0, rows_here);
   TR(5);
 }
 

@@ -48,6 +48,8 @@ struct Mlp3BwdArgs {
   const float* dz3;        // [members][rows][Np3] (zero in padded columns); seed.mode 0 only
   const float* h1;         // [members][rows][256] post-ReLU hidden activations saved by the forward
   const float* h2;
+  const uint32_t* m1;      // [members][ceil(rows/32)][256] sign bits of h1 / h2 written by the forward; when both are
+  const uint32_t* m2;      // given they replace h1 / h2 (which may then be null)
   const float* wt;         // transposed blob (member 0)
   long long t_mstride, w3t, w2t, w1t;
   int Np3, Np1t;

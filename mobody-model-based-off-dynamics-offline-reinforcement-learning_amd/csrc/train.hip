@@ -17,6 +17,7 @@ namespace mobody {
 // workspace carving
 // ------------------------------------------------------------------------------------------------
 struct TrainWs {
+  uint32_t *mq1, *mq2, *ma1, *ma2;      // ReLU sign words of the twin-Q / actor hidden layers
   float *pi, *qt, *q, *qb, *xq, *h1q, *h2q, *xa, *h1a, *h2a, *dz3q, *dz2, *dz1, *dz3a, *dxa, *bcw, *dbp, *slabs, *lossp;
   long long total;
   int nsplit_q, nsplit_a, ntiles, tile_rows;
@@ -41,6 +42,9 @@ static int carve(const MobodyTrainDims& d, float* base, TrainWs& w) {
   w.xa = take(N * w.La.Kp1);
   w.h1a = take(N * HID);
   w.h2a = take(N * HID);
+  const long long mw = cdiv(N, 32) * HID;
+  w.mq1 = (uint32_t*)take(2 * mw); w.mq2 = (uint32_t*)take(2 * mw);
+  w.ma1 = (uint32_t*)take(mw); w.ma2 = (uint32_t*)take(mw);
   w.dz3q = take(2 * N * w.Lq.Np3);
   w.dz2 = take(2 * N * HID);
   w.dz1 = take(2 * N * HID);
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void k_mlp_transpose(MobodyMlpLayout L, const 
 // ------------------------------------------------------------------------------------------------
 static Mlp3FwdArgs fwd_args(const float* blob, const MobodyMlpLayout& L, const float* s0, int n0, const float* s1, int n1,
                             long long rows, float* out, int out_mode, float max_action, float* sx, float* sh1,
-                            float* sh2) {
+                            float* sh2, uint32_t* m1 = nullptr, uint32_t* m2 = nullptr) {
   Mlp3FwdArgs a{};
   a.src[0] = s0; a.ld[0] = n0; a.n[0] = n0;
   a.src[1] = s1; a.ld[1] = n1; a.n[1] = s1 ? n1 : 0;
@@ -226,7 +230,7 @@ static Mlp3FwdArgs fwd_args(const float* blob, const MobodyMlpLayout& L, const f
   a.sw1 = a.sb1 = a.sw2 = a.sb2 = a.sw3 = a.sb3 = L.member_floats;
   a.Kp1 = L.Kp1; a.Np3 = L.Np3; a.nout = L.out_dim; a.rows = rows;
   a.out = out; a.out_mstride = rows * L.out_dim; a.out_ld = L.out_dim;
-  a.save_x = sx; a.save_h1 = sh1; a.save_h2 = sh2;
+  a.save_x = sx; a.save_h1 = sh1; a.save_h2 = sh2; a.mask1 = m1; a.mask2 = m2;
   a.out_mode = out_mode; a.max_action = max_action;
   return a;
 }
@@ -254,9 +258,10 @@ static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h
 }
 
 static Mlp3BwdArgs bwd_args(const MobodyMlpLayout& L, const float* blob_T, const float* dz3, const float* h1,
-                            const float* h2, long long rows, float* dz2, float* dz1, float* dbp) {
+                            const float* h2, long long rows, float* dz2, float* dz1, float* dbp,
+                            const uint32_t* m1 = nullptr, const uint32_t* m2 = nullptr) {
   Mlp3BwdArgs b{};
-  b.dz3 = dz3; b.h1 = h1; b.h2 = h2; b.wt = blob_T; b.t_mstride = L.t_member_floats;
+  b.dz3 = dz3; b.h1 = h1; b.h2 = h2; b.m1 = m1; b.m2 = m2; b.wt = blob_T; b.t_mstride = L.t_member_floats;
   b.w3t = L.w3t; b.w2t = L.w2t; b.w1t = L.w1t; b.Np3 = L.Np3; b.Np1t = L.Np1t; b.rows = rows;
   b.dz2 = dz2; b.dz1 = dz1; b.dbp = dbp;
   return b;
@@ -290,7 +295,7 @@ extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h
   const long long N = d->N;
   const int S = d->S, A = d->A;
   // online twin-Q(s, a), activations kept for the backward (:196), together with a' = pi(s') (:191) in one launch
-  const Mlp3FwdArgs fq = fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q);
+  const Mlp3FwdArgs fq = fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q, w.mq1, w.mq2);
   if (q_next == nullptr) {
     rc = launch_mlp3_fwd_pair(fq, 2, fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pi, 1, h->max_action, nullptr, nullptr, nullptr), 1, st);
     // target twin-Q(s', a')                                                    (:192)
@@ -301,7 +306,7 @@ extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h
   if (rc) return rc;
   const float invNg = 1.f / (float)d->N_global;
   // TD error -> dz3 in the backward's prologue (mobody.py:190-207), then dz2, dz1 and the bias partials
-  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp);
+  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp, w.mq1, w.mq2);
   bq.seed.mode = 1; bq.seed.q = w.q; bq.seed.qt = w.qt; bq.seed.qnext = q_next; bq.seed.r = reward; bq.seed.nd = not_done;
   bq.seed.gamma = h->gamma; bq.seed.inv_ng = invNg; bq.seed.dz3_out = w.dz3q; bq.seed.lossp = w.lossp;
   rc = launch_mlp3_bwd(bq, 2, false, w.tile_rows, st);
@@ -326,9 +331,9 @@ extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper*
   // Q(s_true, a_true) for the BC weights (:251) and pi(s) on the whole mixed batch (its first Nt rows are
   // pi(s_true), mobody.py:249,315) in one launch
   rc = launch_mlp3_fwd_pair(fwd_args(q_blob, w.Lq, state, S, action, A, Nt, w.qb, 0, 1.f, nullptr, nullptr, nullptr), 2,
-                            fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a), 1, st);
-  // Q(s, pi(s)) with the freshly updated critic, activations kept for dQ/da   (:316)
-  if (!rc) rc = launch_mlp3_fwd(fwd_args(q_blob, w.Lq, state, S, w.pi, A, N, w.q, 0, 1.f, nullptr, w.h1q, w.h2q), 2, ACT_RELU, st);
+                            fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2), 1, st);
+  // Q(s, pi(s)) with the freshly updated critic (:316); dQ/da through the frozen net needs only the ReLU signs
+  if (!rc) rc = launch_mlp3_fwd(fwd_args(q_blob, w.Lq, state, S, w.pi, A, N, w.q, 0, 1.f, nullptr, nullptr, nullptr, w.mq1, w.mq2), 2, ACT_RELU, st);
   if (rc) return rc;
   hipLaunchKernelGGL(k_actor_stats, dim3(1), dim3(1024), 0, st, w.q, w.qb, N, Nt, stats);
   MB_LAUNCH_OK("k_actor_stats");
@@ -354,13 +359,13 @@ extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper
   ra.A = d->A; ra.h = *h;
   // dq -> d(action) through the frozen twin-Q (parameters get no gradient, mobody.py:555-556); the prologue forms
   // -p_w/N d min(q1,q2) and the BC weights
-  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, nullptr, w.h1q, w.h2q, N, nullptr, nullptr, w.dbp);
+  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, nullptr, nullptr, nullptr, N, nullptr, nullptr, w.dbp, w.mq1, w.mq2);
   bq.seed.mode = 2; bq.seed.ar = ra;
   bq.dx = w.dxa; bq.dx_c0 = d->S; bq.dx_n = d->A;
   rc = launch_mlp3_bwd(bq, 2, true, w.tile_rows, st);
   if (rc) return rc;
   // actor: d(pre-tanh) from both members' dx and the BC term in the prologue, then the actor's own backward
-  Mlp3BwdArgs ba = bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp);
+  Mlp3BwdArgs ba = bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp, w.ma1, w.ma2);
   ba.seed.mode = 3; ba.seed.ar = ra; ba.seed.dz3_out = w.dz3a; ba.seed.lossp = w.lossp;
   rc = launch_mlp3_bwd(ba, 1, false, w.tile_rows, st);
   if (rc) return rc;
