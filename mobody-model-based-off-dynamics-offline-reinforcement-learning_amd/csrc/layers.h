@@ -7,6 +7,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "tile.h"
 
 namespace mobody {
@@ -19,7 +21,8 @@ namespace mobody {
 // pass of a ReLU net needs only these signs, 32 B per row instead of the 1 KB activation row.
 template <int ACT, int MT = 2, class Extra, class Between>
 __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ W, const float* __restrict__ b, int Kp,
-                                           WideRing& ring, Extra&& extra, Between&& between, uint32_t* mask = nullptr) {
+                                           WideRing& ring, Extra&& extra, Between&& between, uint32_t* mask = nullptr,
+                                           bool full = false) {
   // the wave's two bias values (columns 64w + 32nt + lane&31): requested before the GEMM, consumed after it
   const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
   f32x16 acc[MT][2];
@@ -28,11 +31,21 @@ __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ 
   if (Kp == HID) TR(3);
   between();
   lds_barrier();                         // every wave has finished reading the old image
-  wide_foreach<MT>(acc, [&](int row, int col, float v) {
-    const float y = activate<ACT>(v + ((col & 32) ? bias1 : bias0));
-    Xs[row * LDX + col] = y;
-    extra(row, col, y);
-  });
+  // `full` (wave uniform): every row of the tile is a real row, so `extra` may skip its row guard -- a per-element
+  // row < rows_here test costs a v_cmp plus exec-mask save/restore around each of the 32 stores of a lane
+  if (full) {
+    wide_foreach<MT>(acc, [&](int row, int col, float v) {
+      const float y = activate<ACT>(v + ((col & 32) ? bias1 : bias0));
+      Xs[row * LDX + col] = y;
+      extra(std::false_type{}, row, col, y);
+    });
+  } else {
+    wide_foreach<MT>(acc, [&](int row, int col, float v) {
+      const float y = activate<ACT>(v + ((col & 32) ? bias1 : bias0));
+      Xs[row * LDX + col] = y;
+      extra(std::true_type{}, row, col, y);
+    });
+  }
   if (mask != nullptr) {
     const int i = lane_id() & 31, hh = lane_id() >> 5;
 #pragma unroll
@@ -60,7 +73,8 @@ __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ 
 }
 
 struct NoExtra {
-  __device__ __forceinline__ void operator()(int, int, float) const {}
+  template <class Guard>
+  __device__ __forceinline__ void operator()(Guard, int, int, float) const {}
 };
 
 struct Mlp3FwdArgs {

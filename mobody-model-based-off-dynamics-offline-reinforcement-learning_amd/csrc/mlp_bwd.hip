@@ -48,23 +48,29 @@ __device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], flo
       }
   }
   cs[0] = cs[1] = 0.f;
+  // full tile (wave uniform): no per-element row guard (v_cmp + exec save/restore around each of the 32 stores)
+  auto sweep = [&](auto guarded) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rb = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const int row = 32 * mt + rb;
-        const int col = 64 * w + 32 * nt + i;
-        bool on;
-        if constexpr (BITS) on = (mw[mt][nt] >> rb) & 1u;
-        else on = hv[mt][nt][r] > 0.f;
-        const float dz = (on && row < rows_here) ? acc[mt][nt][r] : 0.f;
-        Xs[row * LDX + col] = dz;
-        if (gdst != nullptr && row < rows_here) gdst[row * HID + col] = dz;
-        cs[nt] += dz;
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int rb = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const int row = 32 * mt + rb;
+          const int col = 64 * w + 32 * nt + i;
+          bool on;
+          if constexpr (BITS) on = (mw[mt][nt] >> rb) & 1u;
+          else on = hv[mt][nt][r] > 0.f;
+          const bool valid = !decltype(guarded)::value || row < rows_here;
+          const float dz = (on && valid) ? acc[mt][nt][r] : 0.f;
+          Xs[row * LDX + col] = dz;
+          if (gdst != nullptr && valid) gdst[row * HID + col] = dz;
+          cs[nt] += dz;
+        }
+  };
+  if (rows_here == 32 * MT) sweep(std::false_type{});
+  else sweep(std::true_type{});
   cs[0] += __shfl_xor(cs[0], 32);
   cs[1] += __shfl_xor(cs[1], 32);
 }

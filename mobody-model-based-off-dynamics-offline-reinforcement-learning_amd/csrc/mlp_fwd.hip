@@ -18,8 +18,9 @@ __device__ __forceinline__ void mlp3_fwd_tail(const Mlp3FwdArgs& a, int m, float
   const float* w3 = a.w3 + m * a.sw3;
   const float* b3 = a.b3 + m * a.sb3;
   float* out = a.out + m * a.out_mstride + row0 * a.out_ld;
-  auto save_h2 = [=](int row, int col, float y) {
-    if (h2 != nullptr && row < rows_here) h2[row * HID + col] = y;
+  const bool full = rows_here == TB;
+  auto save_h2 = [=](auto guarded, int row, int col, float y) {
+    if (h2 != nullptr && (!decltype(guarded)::value || row < rows_here)) h2[row * HID + col] = y;
   };
   auto emit = [&](int row, int col, float v, float bias) {
     if (row < rows_here && col < a.nout) {
@@ -36,11 +37,11 @@ __device__ __forceinline__ void mlp3_fwd_tail(const Mlp3FwdArgs& a, int m, float
     wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [&] {
       narrow_prefetch<NT>(w3, 16 * NT, br);
       bias = b3[mycol < a.nout ? mycol : 0];
-    }, mask2);
+    }, mask2, full);
     TR(4);
     narrow_run<TB / 16, NT>(Xs, br, [&](int row, int col, float v) { emit(row, col, v, bias); });
   } else {
-    wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [] {}, mask2);
+    wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [] {}, mask2, full);
     TR(4);
     narrow_layer(Xs, w3, HID, a.Np3, [&](int row, int col, float v) { emit(row, col, v, b3[col < a.nout ? col : 0]); }, TB);
   }
@@ -70,11 +71,10 @@ __device__ __forceinline__ void mlp3_fwd_tile(const Mlp3FwdArgs& a, int m, float
   tile_zero_cols(Xs, c0, a.Kp1, TB);
   lds_barrier();
   TR(1);
-  if (a.save_x != nullptr && m == 0) {
-    for (int idx = threadIdx.x; idx < rows_here * a.Kp1; idx += NTHREADS * RG) {
-      const int r = idx / a.Kp1, c = idx - r * a.Kp1;
-      a.save_x[(row0 + r) * a.Kp1 + c] = Xs[r * LDX + c];
-    }
+  if (a.save_x != nullptr && m == 0) {              // same thread <-> element map as tile_load (no division)
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    for (int col = c; col < a.Kp1; col += 32)
+      for (int r = r0; r < rows_here; r += (NTHREADS * RG) >> 5) a.save_x[(row0 + r) * a.Kp1 + col] = Xs[r * LDX + col];
   }
 
   float* h1 = a.save_h1 ? a.save_h1 + ((long long)m * a.rows + row0) * HID : nullptr;
@@ -83,8 +83,10 @@ __device__ __forceinline__ void mlp3_fwd_tile(const Mlp3FwdArgs& a, int m, float
   uint32_t* mask1 = a.mask1 ? a.mask1 + mtile : nullptr;
   uint32_t* mask2 = a.mask2 ? a.mask2 + mtile : nullptr;
   wide_layer<ACT, MT>(Xs, w1, a.b1 + m * a.sb1, a.Kp1, ring,
-                      [=](int row, int col, float y) { if (h1 != nullptr && row < rows_here) h1[row * HID + col] = y; },
-                      [&] { wide_prefetch(w2, HID, ring); }, mask1);
+                      [=](auto guarded, int row, int col, float y) {
+                        if (h1 != nullptr && (!decltype(guarded)::value || row < rows_here)) h1[row * HID + col] = y;
+                      },
+                      [&] { wide_prefetch(w2, HID, ring); }, mask1, rows_here == TB);
   TR(2);
   mlp3_fwd_tail<ACT, MT, RG, NT>(a, m, Xs, ring, h2, mask2, row0, rows_here);
   TR(5);

@@ -333,34 +333,30 @@ __device__ __forceinline__ void narrow_run(float* Xs, const NarrowRegs<NT>& br, 
 // --------------------------------------------------------------------------------------------
 __device__ __forceinline__ void tile_load(float* Xs, int col0, const float* __restrict__ src, int ld, int n, int row0,
                                           int rows, int bm = BM) {
-  // Four elements per thread and pass: all loads of a pass are issued before the first LDS write (a load followed
-  // directly by its dependent ds_write costs one HBM round trip per element).  Loads are unconditional from a
-  // clamped row (a conditional load would branch and drain vmcnt per element); invalid rows are zeroed by select.
-  const int total = bm * n;
-  const int nthr = (int)blockDim.x;
-  for (int base = 0; base < total; base += 4 * nthr) {
-    float v[4]; int dst[4]; bool ok[4];
+  // Thread t owns column (t & 31) of every 32-column chunk and rows (t >> 5) + k * (threads/32): no integer division
+  // (an idx / n decode by a runtime n cost ~20 VALU instructions per element, 700+ per wave in the forward prologue).
+  // The four loads of a pass are issued before the first LDS write (a load followed directly by its dependent
+  // ds_write costs one HBM round trip per element); they are unconditional from a clamped row and column (a
+  // conditional load would branch and drain vmcnt per element), invalid rows are zeroed by select.
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5, rstep = (int)blockDim.x >> 5;
+  for (int cb = 0; cb < n; cb += 32) {
+    const int col = cb + c;
+    const int colc = min(col, n - 1);
+    for (int rb = r0; rb < bm; rb += 4 * rstep) {
+      float v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = min(base + u * nthr + (int)threadIdx.x, total - 1);
-      const int r = idx / n, c = idx - r * n;
-      const int gr = row0 + r;
-      v[u] = src[(size_t)min(gr, rows - 1) * ld + c];
-      ok[u] = gr < rows;
-      dst[u] = r * LDX + col0 + c;
+      for (int u = 0; u < 4; ++u) v[u] = src[(size_t)min(row0 + rb + u * rstep, rows - 1) * ld + colc];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = rb + u * rstep;
+        if (col < n && r < bm) Xs[r * LDX + col0 + col] = (row0 + r < rows) ? v[u] : 0.f;
+      }
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (base + u * nthr + (int)threadIdx.x < total) Xs[dst[u]] = ok[u] ? v[u] : 0.f;
   }
 }
 __device__ __forceinline__ void tile_zero_cols(float* Xs, int c0, int c1, int bm = BM) {
-  const int n = c1 - c0;
-  if (n <= 0) return;
-  for (int idx = threadIdx.x; idx < bm * n; idx += (int)blockDim.x) {
-    const int r = idx / n, c = idx - r * n;
-    Xs[r * LDX + c0 + c] = 0.f;
-  }
+  for (int r = threadIdx.x; r < bm; r += (int)blockDim.x)
+    for (int c = c0; c < c1; ++c) Xs[r * LDX + c] = 0.f;
 }
 
 __host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
