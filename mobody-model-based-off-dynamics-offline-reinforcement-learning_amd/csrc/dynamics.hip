@@ -29,7 +29,8 @@ struct DynFwdArgs {
   int use_trg;
 };
 
-template <int MT>
+// NT3: 16-column tiles of the transition head handled by the K-split narrow layer (Np == 16*NT3), 0 = any width.
+template <int MT, int NT3>
 __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   constexpr int TB = 32 * MT;
@@ -42,11 +43,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   auto Bp = [&](int l) { return a.blob + a.L.layer[l].b_off + (long long)e * a.L.layer[l].Np; };
 
   // ---- state encoder: zs = mu-half of zs3(Sw(zs2(Sw(zs1(s)))))   (encode_state :217-225) ----
+  // every wide layer's first weight fragments are requested one phase early (see wide_prefetch)
+  WideRing ring;
+  wide_prefetch(Wp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, ring);
   tile_load(Xs, 0, a.obs + row0 * S, S, S, 0, rows_here, TB);
   tile_zero_cols(Xs, S, a.L.layer[MOBODY_DL_ZS1].Kp, TB);
   lds_barrier();
-  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, NoExtra{});
-  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS2), Bp(MOBODY_DL_ZS2), HID, NoExtra{});
+  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, ring, NoExtra{},
+                            [&] { wide_prefetch(Wp(MOBODY_DL_ZS2), HID, ring); });
+  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS2), Bp(MOBODY_DL_ZS2), HID, ring, NoExtra{}, [] {});
 
   // From here to the latent sum every wave works on its own 16 rows: no barriers needed (waves without rows idle).
   if (16 * w < TB) {
@@ -88,13 +93,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   lds_barrier();
 
   // ---- transition decoder   (encode_transition :287-293) ----
-  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, NoExtra{});
-  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, NoExtra{});
+  wide_prefetch(Wp(MOBODY_DL_TR1), 16, ring);
+  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, ring, NoExtra{},
+                            [&] { wide_prefetch(Wp(MOBODY_DL_TR2), HID, ring); });
   const float* b3 = Bp(MOBODY_DL_TR3);
   float* mean = a.mean + ((long long)e * a.B + row0) * S;
-  narrow_layer(Xs, Wp(MOBODY_DL_TR3), HID, a.L.layer[MOBODY_DL_TR3].Np, [&](int row, int col, float v) {
-    if (row < rows_here && col < S) mean[row * S + col] = v + b3[col];
-  }, TB);
+  if constexpr (NT3 > 0) {
+    NarrowRegs<NT3> br;
+    const int mycol = threadIdx.x % (16 * NT3);          // column of every output element this thread finishes
+    float bias;
+    wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, ring, NoExtra{}, [&] {
+      narrow_prefetch<NT3>(Wp(MOBODY_DL_TR3), 16 * NT3, br);
+      bias = b3[mycol < S ? mycol : 0];
+    });
+    narrow_run<TB / 16, NT3>(Xs, br, [&](int row, int col, float v) {
+      if (row < rows_here && col < S) mean[row * S + col] = v + bias;
+    });
+  } else {
+    wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, ring, NoExtra{}, [] {});
+    narrow_layer(Xs, Wp(MOBODY_DL_TR3), HID, a.L.layer[MOBODY_DL_TR3].Np, [&](int row, int col, float v) {
+      if (row < rows_here && col < S) mean[row * S + col] = v + b3[col];
+    }, TB);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -193,17 +213,17 @@ __global__ __launch_bounds__(256) void k_dyn_finalize(DynFinalArgs a) {
   a.reward[b] = (a.coef != 0.f) ? raw - a.coef * a.penalty[b] : raw;       // :261-263
 }
 
-template <int MT>
+template <int MT, int NT3>
 static int launch_dyn_fwd_t(const DynFwdArgs& a, hipStream_t st) {
   constexpr size_t lds = (size_t)32 * MT * LDX * sizeof(float);
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_dyn_fwd<MT>, lds);
+    int rc = allow_big_lds(k_dyn_fwd<MT, NT3>, lds);
     if (rc) return rc;
     once = true;
   }
   ProfScope prof(PROF_DYN_FWD, st);
-  hipLaunchKernelGGL(k_dyn_fwd<MT>, dim3((unsigned)cdiv(a.B, 32 * MT), NENS), dim3(NTHREADS), lds, st, a);
+  hipLaunchKernelGGL((k_dyn_fwd<MT, NT3>), dim3((unsigned)cdiv(a.B, 32 * MT), NENS), dim3(NTHREADS), lds, st, a);
   MB_LAUNCH_OK("k_dyn_fwd");
   return 0;
 }
@@ -214,7 +234,10 @@ static int launch_dyn_fwd(const float* blob, const MobodyDynLayout& L, const flo
   // 64-row tiles here: the nine-layer chain has a wave-local narrow section in which a 32-row tile idles half of
   // the waves (measured 102 vs 88 TFLOP/s at 50 000 rows); MOBODY_DYN_TILE_ROWS=32 selects the short tile.
   static const bool short_tile = [] { const char* e = getenv("MOBODY_DYN_TILE_ROWS"); return e && atoi(e) == 32; }();
-  return short_tile ? launch_dyn_fwd_t<1>(a, st) : launch_dyn_fwd_t<2>(a, st);
+  const int np = L.layer[MOBODY_DL_TR3].Np;
+  const int nt3 = np == 16 ? 1 : np == 32 ? 2 : 0;
+  if (short_tile) return nt3 == 1 ? launch_dyn_fwd_t<1, 1>(a, st) : nt3 == 2 ? launch_dyn_fwd_t<1, 2>(a, st) : launch_dyn_fwd_t<1, 0>(a, st);
+  return nt3 == 1 ? launch_dyn_fwd_t<2, 1>(a, st) : nt3 == 2 ? launch_dyn_fwd_t<2, 2>(a, st) : launch_dyn_fwd_t<2, 0>(a, st);
 }
 
 }  // namespace mobody
