@@ -208,12 +208,15 @@ def main():
         # HBM bytes of one launch of the dominant kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE passes, committed under profiles/; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")))
             fam = [e for e in pm if dom in e["kernel"] and e["fetch_kb_raw"] and e["write_kb"]]
             if fam and bs == BS:
-                e = max(fam, key=lambda e: e["launches"])
-                roofline["traffic"] = (2.0 * e["fetch_kb_raw"] + e["write_kb"]) * 1024.0
-                roofline["traffic_note"] = f"PMC avg over {e['launches']} launches of {e['kernel'].strip()} grid {e['grid']}"
+                top = max(e["launches"] for e in fam)
+                fam = [e for e in fam if 2 * e["launches"] >= top]          # the train() step's launches of this family
+                n = sum(e["launches"] for e in fam)
+                roofline["traffic"] = sum((2.0 * e["fetch_kb_raw"] + e["write_kb"]) * 1024.0 * e["launches"] for e in fam) / n
+                roofline["traffic_note"] = "PMC launch-weighted mean over " + "; ".join(
+                    f"{e['launches']} x {e['kernel'].strip()} grid {e['grid']}" for e in fam)
         except Exception:
             pass
         out = {
