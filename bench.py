@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch_size", type=int, default=BS)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--graph", type=int, default=1, help="HIP-graph replay of the steady-state step: 0 never, 1 always, 2 auto (minibatches under 4096 rows); 1 GPU only")
+    ap.add_argument("--graph", type=int, default=1, help="HIP-graph replay of the steady-state step: 0 never, 1 always, 2 auto (minibatches under 4096 rows); with N > 1 ranks the segments between the three all-reduces are replayed")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -226,7 +226,7 @@ def main():
             "config": {"workload": f"walker2d-friction shapes S={S} A={A}, ensemble 7, rollout_len 1, batch_size {bs}/GPU "
                                    f"(N={N} rows per train() step: src|tar|fake = {bs}|{bs}|{bs // 2}), fp32 MFMA",
                        "rows_per_step_per_gpu": N, "parallelism": f"dp{world}",
-                       "hip_graph": bool(world == 1 and (args.graph == 1 or (args.graph == 2 and N < 4096)))},
+                       "hip_graph": bool(args.graph == 1 or (args.graph == 2 and N < 4096))},
             "grad_steps_per_sec": args.steps / dt,
             "rollout_transitions_per_sec": roll_rate, "rollout_ms_per_50000": roll_ms,
             "rollout_refresh_amortised_ms_per_step": (152000.0 / roll_rate) * 1e3 / 5000.0,

@@ -343,43 +343,76 @@ class MOBODY(object):
     # ------------------------------------------------------------------ training
     # ------------------------------------------------------------------ HIP-graph fast path
     def _graph_ok(self, writer):
-        d = torch.distributed
         want = self.use_graph == 1 or (self.use_graph == 2 and self._batch[0].shape[0] < 4096)
         return (want and self.rng == "device" and self.penalty_type not in ("par", "dara")
                 and not self.config["advantage"] and (self.total_it - 1) % REFRESH_EVERY != 0
-                and not (writer is not None and self.total_it % 5000 == 0)
-                and not (d.is_available() and d.is_initialized() and d.get_world_size() > 1))
+                and not (writer is not None and self.total_it % 5000 == 0))
 
-    def _graph_body(self, src, tar, batch_size):
+    @staticmethod
+    def _world():
+        d = torch.distributed
+        return d.get_world_size() if d.is_available() and d.is_initialized() else 1
+
+    def _graph_segments(self, src, tar, batch_size, world):
+        """The steady-state step as a list of closures that only enqueue kernels.  One rank: a single segment.  Data
+        parallel: the four segments between the three collectives of mobody_amd/dp.py (the all-reduces themselves are
+        issued eagerly between the replays, on the same stream)."""
         cfg, S, A = self.config, self.S, self.A
         ns, nt = int(cfg["src_ratio"] * batch_size), int(cfg["trg_ratio"] * batch_size)
         nf = int(cfg["fake_batch_scale"] * batch_size) if cfg["fake_batch_scale"] != 0 else 0
         N, Nt = ns + nt + nf, ns + nt
-        c = self._ctr
-        ops.counter_add(c)
+        Ng, Ntg = N * world, Nt * world
+        c, b = self._ctr, self._batch
         bufs, cnts, seeds = [src, tar], [ns, nt], [self.seed + 101, self.seed + 102]
         if nf > 0:
             bufs.append(self.fake_replay_buffer); cnts.append(nf); seeds.append(self.seed + 103)
-        ops.gather_batch_rng([b._fields() for b in bufs], cnts, seeds, [0] * len(bufs), c[0:1],
-                             [b.ptr_size[1:2] for b in bufs], S, A, self._batch)
-        b = self._batch
-        self.critic_grad(b, N, Nt, N, Nt)
-        self.q_optimizer.step_dev(c[1:2], target=self.target_q_funcs, tau=self.tau)
-        self.actor_stats(b, N, Nt, N, Nt)
-        self.actor_grad(b, N, Nt, N, Nt)
-        self.policy_optimizer.step_dev(c[2:3])
+
+        def critic():
+            ops.counter_add(c)
+            ops.gather_batch_rng([rb._fields() for rb in bufs], cnts, seeds, [0] * len(bufs), c[0:1],
+                                 [rb.ptr_size[1:2] for rb in bufs], S, A, b)
+            self.critic_grad(b, N, Nt, Ng, Ntg)
+
+        def critic_apply_actor_stats():
+            self.q_optimizer.step_dev(c[1:2], target=self.target_q_funcs, tau=self.tau)
+            self.actor_stats(b, N, Nt, Ng, Ntg)
+
+        def actor():
+            self.actor_grad(b, N, Nt, Ng, Ntg)
+
+        def actor_apply():
+            self.policy_optimizer.step_dev(c[2:3])
+
+        if world == 1:
+            return [lambda: (critic(), critic_apply_actor_stats(), actor(), actor_apply())]
+        return [critic, critic_apply_actor_stats, actor, actor_apply]
 
     def _graph_step(self, src, tar, batch_size):
-        key = (batch_size, id(src), id(tar), src.state.data_ptr(), tar.state.data_ptr())
+        world = self._world()
+        key = (batch_size, id(src), id(tar), src.state.data_ptr(), tar.state.data_ptr(), world)
         if self._graph is None or self._graph_key != key:
             torch.cuda.synchronize()
             self._ctr[1] = self.q_optimizer.t
             self._ctr[2] = self.policy_optimizer.t
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._graph_body(src, tar, batch_size)
-            self._graph, self._graph_key = g, key
-        self._graph.replay()
+            graphs = []
+            for seg in self._graph_segments(src, tar, batch_size, world):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    seg()
+                graphs.append(g)
+            self._graph, self._graph_key = graphs, key
+        if world == 1:
+            self._graph[0].replay()
+        else:                                           # exchange protocol of dp.dp_update, segments replayed
+            d = torch.distributed
+            ga, gb, gc, gd = self._graph
+            ga.replay()
+            d.all_reduce(self.q_optimizer.grad)
+            gb.replay()
+            d.all_reduce(self._stats)
+            gc.replay()
+            d.all_reduce(self.policy_optimizer.grad)
+            gd.replay()
         self.q_optimizer.t += 1
         self.policy_optimizer.t += 1
 

@@ -1,0 +1,92 @@
+"""Data-parallel train() on the GPU box: two ranks sharing the one GPU, gloo exchanges (RCCL refuses two ranks on one
+device), through the product mirror.  Checks (a) replicas stay bit-identical, (b) the segment-graph replay of the
+steady-state step (graphs between the three collectives) equals the eager exchange protocol fed with the same draws,
+(c) parameters moved and are finite."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, tmp):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+    import torch.distributed as dist
+    import golden_util as gu
+    from mobody_amd import synthetic
+    from mobody_amd.algo import utils
+    from mobody_amd.algo.call_algo import call_algo
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    S, A, bs, task = 17, 6, 256, "walker2d-medium-v2"
+
+    def make(graph):
+        cfg = gu.policy_cfg(S, A, rng="device", seed=rank, penalty_type="none", batch_size=bs, graph=graph,
+                            fake_batch_scale=0.5)
+        torch.manual_seed(0); np.random.seed(0)                   # same initial weights on every rank
+        pol = call_algo("mobody", cfg, 3, dev)
+        pa, pq, _ = gu.policy_params(5, S, A)
+        pol.policy.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
+        pol.q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+        pol.target_q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+        src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=4000, rng="device", seed=100 + rank), 4000, task, rank)
+        tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=500, rng="device", seed=200 + rank), 500, task, 50 + rank)
+        fake = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=3000, rng="device", seed=300 + rank), 3000, task, 90 + rank)
+        pol.fake_replay_buffer = fake
+        pol.total_it = 1                                           # past the refresh step (no dynamics model here)
+        return pol, src, tar
+
+    from mobody_amd import ops
+    out = {}
+    for graph in (0, 1):
+        pol, src, tar = make(graph)
+        pol.train(src, tar, bs, None, None)                        # first call: eager in both modes (allocates the batch)
+        for call in (1, 2, 3):
+            if graph:
+                pol.train(src, tar, bs, None, None)                # segment graphs + eager all-reduces
+            else:                                                  # the graphs' index draws (call ids 1..3), eager protocol
+                pol.total_it += 1
+                c = torch.tensor([call], dtype=torch.int64, device=dev)
+                fb = pol.fake_replay_buffer
+                idx = [ops.sample_indices(rank + 101, 3, c, 0, bs, src.ptr_size[1:2]),
+                       ops.sample_indices(rank + 102, 3, c, 0, bs, tar.ptr_size[1:2]),
+                       ops.sample_indices(rank + 103, 3, c, 0, bs // 2, fb.ptr_size[1:2])]
+                ops.gather_batch([src._fields(), tar._fields(), fb._fields()], idx, S, A, out=pol._batch)
+                pol._update(pol._batch, int(2.5 * bs), 2 * bs)
+        torch.cuda.synchronize()
+        assert (pol._graph is not None) == bool(graph)
+        if graph:
+            assert len(pol._graph) == 4 and pol._ctr.tolist() == [3, 4, 4]
+        out[graph] = {k: v.cpu() for k, v in list(pol.policy.state_dict().items()) + list(pol.q_funcs.state_dict().items())
+                      + [("t." + k, v) for k, v in pol.target_q_funcs.state_dict().items()]}
+        out[graph]["losses"] = torch.tensor(pol.losses())
+    torch.save(out, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_eager_equals_segment_graphs(tmp_path):
+    port = 29500 + os.getpid() % 400
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in (0, 1))
+    import golden_util as gu
+    _, pq, _ = gu.policy_params(5, 17, 6)
+    for graph in (0, 1):
+        for k in r0[graph]:
+            if k == "losses":
+                continue                                            # local shares differ per rank by construction
+            assert torch.equal(r0[graph][k], r1[graph][k]), (graph, k, float((r0[graph][k] - r1[graph][k]).abs().max()))  # replicas in sync
+            assert torch.isfinite(r0[graph][k]).all()
+    # replay == eager protocol; the device-side Adam bias corrections use the GPU's double pow, the host path libm:
+    # allow 1 ulp of fp32
+    for k in r0[0]:
+        if k != "losses":
+            np.testing.assert_allclose(r0[1][k].numpy(), r0[0][k].numpy(), rtol=1e-6, atol=1e-8, err_msg=k)
+    k = "network1.network.0.weight"
+    assert not np.allclose(r0[0][k].numpy(), pq[k])                         # and the step did something
