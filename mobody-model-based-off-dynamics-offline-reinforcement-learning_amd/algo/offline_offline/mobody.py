@@ -395,11 +395,19 @@ class MOBODY(object):
             self._ctr[1] = self.q_optimizer.t
             self._ctr[2] = self.policy_optimizer.t
             graphs = []
-            for seg in self._graph_segments(src, tar, batch_size, world):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    seg()
-                graphs.append(g)
+            try:
+                for seg in self._graph_segments(src, tar, batch_size, world):
+                    g = torch.cuda.CUDAGraph()
+                    # thread-local capture: the process group's watchdog thread may touch the runtime meanwhile
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        seg()
+                    graphs.append(g)
+            except Exception as exc:                   # capture refused: stay on the eager path for good
+                import warnings
+                warnings.warn(f"HIP-graph capture of the train() step failed ({exc!r}); continuing eagerly")
+                self.use_graph, self._graph = 0, None
+                torch.cuda.synchronize()
+                return False
             self._graph, self._graph_key = graphs, key
         if world == 1:
             self._graph[0].replay()
@@ -415,14 +423,15 @@ class MOBODY(object):
             gd.replay()
         self.q_optimizer.t += 1
         self.policy_optimizer.t += 1
+        return True
 
     def train(self, src_replay_buffer, tar_replay_buffer, batch_size=128, writer=None, wandbrun=None):
         """One gradient step, mobody.py:347-578."""
         cfg = self.config
         self.total_it += 1
         self.src_replay_buffer, self.tar_replay_buffer = src_replay_buffer, tar_replay_buffer
-        if self._batch is not None and self._graph_ok(writer):
-            return self._graph_step(src_replay_buffer, tar_replay_buffer, batch_size)
+        if self._batch is not None and self._graph_ok(writer) and self._graph_step(src_replay_buffer, tar_replay_buffer, batch_size):
+            return
         if self._graph is not None:                       # an eager step (refresh/logging) moves the host-side counts
             self._graph = None
         if self.penalty_type == "dara" and self.total_it == 1:
