@@ -94,6 +94,19 @@ class MOBODYEnsembleDynamics(object):
         terminal = r["terminal"].cpu().numpy().astype(bool)            # the reference returns host NumPy (:237)
         return r["next_obs"], r["reward"], terminal, info
 
+    def model_error(self, obs, action, next_obs, reward):
+        """Model error on real transitions as eval_policy_batch reports it (train_mobody.py:100-133):
+        one `step(obs, action, False)` (no penalty, target model), then
+        obs_mse = mean_rows ||next_obs_model - next_obs||_2 and reward_mse = mean (reward - reward_model)^2.
+        Returns device scalars plus the per-row distances."""
+        dev = self.model.device
+        nxt = torch.as_tensor(next_obs, dtype=torch.float32).to(dev)
+        rew = torch.as_tensor(reward, dtype=torch.float32).to(dev).reshape(-1)
+        r = self.step_device(obs, action, False)
+        dist = torch.sqrt(torch.sum((r["next_obs"] - nxt) ** 2, dim=1))
+        return {"obs_mse": dist.mean(), "obs_mse_individual": dist,
+                "reward_mse": torch.mean((rew - r["reward"].reshape(-1)) ** 2), "penalty": r["penalty"]}
+
     def train(self, *a, **k):
         raise NotImplementedError("dynamics pre-training (mobody_dynamics.py:731-978) is the first 'next' row of "
                                   "SURVEY 8(f); load a pretrained dynamics with .load(dir)")

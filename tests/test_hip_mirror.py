@@ -180,6 +180,31 @@ def test_device_rollout_into_fake_buffer_matches_oracle(dev):
         close(t[:K], np.concatenate(want[k], 0))
 
 
+def test_model_error_on_real_transitions_vs_oracle(dev):
+    """the evaluation-side model error (train_mobody.py:100-133) reuses the ensemble step."""
+    S, A, B = 17, 6, 333
+    p = gu.gi.dyn_params(201, S, A)
+    p["transition3.bias"][:, 0, 0] += np.float32(1.0)
+    cfg = gu.policy_cfg(S, A)
+    dyn = make_dynamics(p, S, A, "walker2d-medium-v2", dev, cfg)
+    rng = np.random.default_rng(12)
+    obs = gu.gi.walker_like_obs(rng, B, S); act = rng.uniform(-1, 1, (B, A)).astype(np.float32)
+    nxt = gu.gi.walker_like_obs(rng, B, S); rew = rng.standard_normal(B).astype(np.float32)
+    eps = rng.standard_normal((7, B, S)).astype(np.float32)
+    feed(dyn, [eps])
+    np.random.seed(5)
+    got = dyn.model_error(obs, act, nxt, rew)
+    np.random.seed(5)
+    idx = dyn.model.random_elite_idxs(B)
+    with torch.no_grad():
+        want = O.dyn_step(O.to_torch(p), obs, act, eps, idx, "walker2d-medium-v2",
+                          penalty_coef=0.1, use_penalty=False)
+    d = np.sqrt(((want["next_obs"].numpy() - nxt) ** 2).sum(1))
+    close(got["obs_mse_individual"], d)
+    close(got["obs_mse"], d.mean())
+    close(got["reward_mse"], ((rew - want["reward"].numpy()[:, 0]) ** 2).mean(), rtol=1e-5, atol=1e-6)
+
+
 def test_first_train_call_refreshes_fake_buffer_and_checkpoints_round_trip(dev, tmp_path):
     from mobody_amd import synthetic
     from mobody_amd.algo import utils
