@@ -1,0 +1,58 @@
+"""The CLI mirror (mobody_amd/train_mobody.py) against the reference's own argparse table (fixture g10, extracted
+from the reference source text by tests/golden/make_cli_golden.py), and one short end-to-end run on the GPU."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_flags_match_the_reference_table():
+    from mobody_amd import train_mobody as tm
+    want = {f["flag"]: f for f in json.load(open(os.path.join(ROOT, "tests", "golden", "g10_cli_flags.json")))}
+    got = {a.option_strings[0]: a for a in tm.build_parser()._actions if a.option_strings and a.option_strings[0] != "-h"}
+    extra = {"--synthetic", "--rng", "--src_rows", "--tar_rows", "--log_every"}            # additions of this build
+    assert set(got) - extra == set(want)
+    for flag, f in want.items():
+        a = got[flag]
+        if f["action"] == "store_true":
+            assert a.const is True and a.default is False, flag
+            continue
+        assert a.default == f["default"] and type(a.default) is type(f["default"]), (flag, a.default, f["default"])
+        assert (a.type.__name__ if a.type is not None else None) == f["type"], flag
+
+
+def test_config_merge_precedence():
+    """yaml <- --params JSON <- CLI-derived keys (train_mobody.py:407-416, 470-531)."""
+    from mobody_amd import train_mobody as tm
+    args = tm.build_parser().parse_args(["--policy", "MOBODY", "--env", "walker2d-friction", "--shift_level", "2.0",
+                                         "--params", '{"batch_size": 64, "bc_coef": 9.0}', "--bc_coef", "0.5",
+                                         "--penalty_type", "none", "--scale_q", "0"])
+    cfg = tm.build_config(args, 17, 6, 1.0)
+    assert cfg["batch_size"] == 64                      # --params overrides the yaml
+    assert cfg["bc_coef"] == 0.5                        # CLI-derived keys override --params
+    assert cfg["shift_level"] == 2.0 and cfg["state_dim"] == 17 and cfg["action_dim"] == 6
+    assert cfg["penalty_type"] == "none" and cfg["scale_Q"] == 0 and cfg["weight"] == 2.5 and cfg["tau"] == 0.005
+    with pytest.raises(NotImplementedError):
+        tm.domain_of("reacher-x")
+
+
+@pytest.mark.gpu
+def test_cli_runs_end_to_end_on_synthetic_buffers(tmp_path, capsys):
+    import torch
+    from mobody_amd import train_mobody as tm
+    pol = tm.main(["--policy", "MOBODY", "--env", "walker2d_friction", "--shift_level", "2.0", "--mode", "3", "--seed", "1",
+                   "--synthetic", "1", "--rng", "device", "--penalty_type", "none", "--src_rows", "20000", "--tar_rows", "2000",
+                   "--src_rollout_batch_size", "4000", "--trg_rollout_batch_size", "1000", "--max_step", "12",
+                   "--params", '{"batch_size": 256, "max_step": 12, "eval_freq": 10}', "--log_every", "6",
+                   "--dir", str(tmp_path), "--save-model", "--eval_freq", "10"])
+    out = capsys.readouterr().out
+    assert pol.total_it == 12 and "step 12:" in out and "grad-steps/s" in out
+    q, pi, bc = pol.losses()
+    assert all(map(lambda v: v == v and abs(v) < 1e6, (q, pi, bc)))
+    assert pol.fake_replay_buffer.size > 0                       # the step-1 refresh filled the fake buffer
+    models = os.path.join(str(tmp_path), "MOBODY", "walker2d-friction-srcdatatype-medium-tardatatype-medium-2.0", "r1", "models")
+    assert sorted(os.listdir(models)) == ["model_actor", "model_actor_optimizer", "model_critic", "model_critic_optimizer"]
+    sd = torch.load(os.path.join(models, "model_actor"), weights_only=True)
+    assert sorted(sd) == sorted(f"network.network.{i}.{w}" for i in (0, 2, 4) for w in ("weight", "bias"))
