@@ -101,6 +101,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own HIP runtime; it has to be in the process BEFORE this library is mapped so that both bind
+    # to the same runtime instance (the reverse order left the kernels with "no ROCm-capable device is detected").
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python {os.path.join(_HERE, 'csrc', 'build.py')}` "
