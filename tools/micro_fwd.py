@@ -25,7 +25,7 @@ def timeit(fn, reps=50):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for rows in (32, 64, 640, 2560, 10240, 40960):
+for rows in [int(x) for x in sys.argv[1:]] or (32, 64, 640, 2560, 10240, 40960):
     s = torch.randn(rows, S, device=dev); a = torch.rand(rows, A, device=dev)
     t_actor = timeit(lambda: ops.mlp3_forward(ab, S, A, 1, s, out_mode=1))
     t_q = timeit(lambda: ops.mlp3_forward(qb, S + A, 1, 2, s, a))
