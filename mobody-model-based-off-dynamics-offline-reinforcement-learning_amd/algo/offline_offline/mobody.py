@@ -199,6 +199,7 @@ class MOBODY(object):
         # config['graph']: 0 never, 1 always, 2 auto (replay pays off for launch-bound steps, i.e. small minibatches)
         self.use_graph = int(config.get("graph", 0))
         self._graph, self._graph_key = None, None
+        self._force_segments = False           # test hook: replay the data-parallel segments even with one rank
         self._ctr = torch.zeros(3, dtype=torch.int64, device=self.device)      # [rng call, critic t, actor t]
 
     # ------------------------------------------------------------------ acting
@@ -353,7 +354,7 @@ class MOBODY(object):
         d = torch.distributed
         return d.get_world_size() if d.is_available() and d.is_initialized() else 1
 
-    def _graph_segments(self, src, tar, batch_size, world):
+    def _graph_segments(self, src, tar, batch_size, world, segmented):
         """The steady-state step as a list of closures that only enqueue kernels.  One rank: a single segment.  Data
         parallel: the four segments between the three collectives of mobody_amd/dp.py (the all-reduces themselves are
         issued eagerly between the replays, on the same stream)."""
@@ -383,20 +384,21 @@ class MOBODY(object):
         def actor_apply():
             self.policy_optimizer.step_dev(c[2:3])
 
-        if world == 1:
+        if not segmented:
             return [lambda: (critic(), critic_apply_actor_stats(), actor(), actor_apply())]
         return [critic, critic_apply_actor_stats, actor, actor_apply]
 
     def _graph_step(self, src, tar, batch_size):
         world = self._world()
-        key = (batch_size, id(src), id(tar), src.state.data_ptr(), tar.state.data_ptr(), world)
+        segmented = world > 1 or (self._force_segments and torch.distributed.is_initialized())
+        key = (batch_size, id(src), id(tar), src.state.data_ptr(), tar.state.data_ptr(), world, segmented)
         if self._graph is None or self._graph_key != key:
             torch.cuda.synchronize()
             self._ctr[1] = self.q_optimizer.t
             self._ctr[2] = self.policy_optimizer.t
             graphs = []
             try:
-                for seg in self._graph_segments(src, tar, batch_size, world):
+                for seg in self._graph_segments(src, tar, batch_size, world, segmented):
                     g = torch.cuda.CUDAGraph()
                     # thread-local capture: the process group's watchdog thread may touch the runtime meanwhile
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
@@ -409,7 +411,7 @@ class MOBODY(object):
                 torch.cuda.synchronize()
                 return False
             self._graph, self._graph_key = graphs, key
-        if world == 1:
+        if not segmented:
             self._graph[0].replay()
         else:                                           # exchange protocol of dp.dp_update, segments replayed
             d = torch.distributed

@@ -90,3 +90,43 @@ def test_two_rank_train_eager_equals_segment_graphs(tmp_path):
             np.testing.assert_allclose(r0[1][k].numpy(), r0[0][k].numpy(), rtol=1e-6, atol=1e-8, err_msg=k)
     k = "network1.network.0.weight"
     assert not np.allclose(r0[0][k].numpy(), pq[k])                         # and the step did something
+
+
+def _nccl_worker(rank, world, port, tmp):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+    import torch.distributed as dist
+    import golden_util as gu
+    from mobody_amd import synthetic
+    from mobody_amd.algo import utils
+    from mobody_amd.algo.call_algo import call_algo
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    S, A, bs, task = 17, 6, 256, "walker2d-medium-v2"
+    res = {}
+    for mode in ("single", "segments"):
+        cfg = gu.policy_cfg(S, A, rng="device", seed=3, penalty_type="none", batch_size=bs, graph=1)
+        torch.manual_seed(0); np.random.seed(0)
+        pol = call_algo("mobody", cfg, 3, dev)
+        pol._force_segments = mode == "segments"
+        src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=4000, rng="device", seed=100), 4000, task, 0)
+        tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=500, rng="device", seed=200), 500, task, 50)
+        pol.fake_replay_buffer = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=3000, rng="device", seed=300), 3000, task, 90)
+        pol.total_it = 1
+        for _ in range(6):
+            pol.train(src, tar, bs, None, None)
+        torch.cuda.synchronize()
+        assert len(pol._graph) == (4 if mode == "segments" else 1)
+        res[mode] = {k: v.cpu() for k, v in list(pol.policy.state_dict().items()) + list(pol.q_funcs.state_dict().items())}
+    torch.save(res, os.path.join(tmp, "nccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_segment_replay_with_rccl_process_group_single_rank(tmp_path):
+    """Graph capture and replay next to a live RCCL process group (watchdog thread, communicator streams): one rank,
+    the four-segment replay with real `nccl` all-reduces between the graphs equals the single-graph step bit for bit."""
+    port = 29900 + os.getpid() % 90
+    mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "nccl.pt")
+    for k in r["single"]:
+        assert torch.equal(r["single"][k], r["segments"][k]), k
