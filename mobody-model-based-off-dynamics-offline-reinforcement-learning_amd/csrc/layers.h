@@ -17,12 +17,13 @@ namespace mobody {
 // `ring` holds wide_prefetch(W, Kp); `between()` runs after the last MFMA and before the epilogue -- the place to
 // request the NEXT layer's first weight fragments (the ring's registers are free again), so their L2/HBM round trip
 // overlaps this layer's barrier + epilogue instead of stalling the next GEMM.
-// `mask` (optional): this tile's [MT][256] words; bit r of word (mt, col) = [y(row 32 mt + r, col) > 0].  The backward
+// `mask` (optional): this tile's [groups][256] words, `mask_groups` of them real; bit r of word (g, col) =
+// [y(row 32 g + r, col) > 0].  The backward
 // pass of a ReLU net needs only these signs, 32 B per row instead of the 1 KB activation row.
 template <int ACT, int MT = 2, class Extra, class Between>
 __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ W, const float* __restrict__ b, int Kp,
                                            WideRing& ring, Extra&& extra, Between&& between, uint32_t* mask = nullptr,
-                                           bool full = false) {
+                                           bool full = false, int mask_groups = 1 << 30) {
   // the wave's two bias values (columns 64w + 32nt + lane&31): requested before the GEMM, consumed after it
   const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
   f32x16 acc[MT][2];
@@ -58,7 +59,9 @@ __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ 
         for (int r = 0; r < 16; ++r)
           word |= (uint32_t)(activate<ACT>(acc[mt][nt][r] + bias) > 0.f) << ((r & 3) + 8 * (r >> 2) + 4 * hh);
         word |= (uint32_t)__shfl_xor((int)word, 32);        // the other lane half holds the other 16 rows
-        if (hh == 0) mask[(32 * MT * wave_rg() / 32 + mt) * HID + 64 * wave_col() + 32 * nt + i] = word;
+        // 32-row groups past the end of the batch have no words (a taller tile's last groups would land in the next member)
+        const int grp = MT * wave_rg() + mt;
+        if (hh == 0 && grp < mask_groups) mask[grp * HID + 64 * wave_col() + 32 * nt + i] = word;
       }
   }
   lds_barrier();

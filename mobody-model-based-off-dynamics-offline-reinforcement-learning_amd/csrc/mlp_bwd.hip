@@ -35,7 +35,10 @@ __device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], flo
   uint32_t mw[MT][2];
   if constexpr (BITS) {                            // two words per 32-row tile and lane instead of 32 activations
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { mw[mt][0] = bits[mt * HID + 64 * w + i]; mw[mt][1] = bits[mt * HID + 64 * w + 32 + i]; }
+    for (int mt = 0; mt < MT; ++mt) {
+      const int g = min(mt, (rows_here + 31) / 32 - 1);      // groups past the end of the batch have no words (their rows are masked)
+      mw[mt][0] = bits[g * HID + 64 * w + i]; mw[mt][1] = bits[g * HID + 64 * w + 32 + i];
+    }
   } else {
     const float* hp = h + 64 * w + i;
 #pragma unroll

@@ -37,11 +37,11 @@ __device__ __forceinline__ void mlp3_fwd_tail(const Mlp3FwdArgs& a, int m, float
     wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [&] {
       narrow_prefetch<NT>(w3, 16 * NT, br);
       bias = b3[mycol < a.nout ? mycol : 0];
-    }, mask2, full);
+    }, mask2, full, (rows_here + 31) / 32);
     TR(4);
     narrow_run<TB / 16, NT>(Xs, br, [&](int row, int col, float v) { emit(row, col, v, bias); });
   } else {
-    wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [] {}, mask2, full);
+    wide_layer<ACT, MT>(Xs, a.w2 + m * a.sw2, a.b2 + m * a.sb2, HID, ring, save_h2, [] {}, mask2, full, (rows_here + 31) / 32);
     TR(4);
     narrow_layer(Xs, w3, HID, a.Np3, [&](int row, int col, float v) { emit(row, col, v, b3[col < a.nout ? col : 0]); }, TB);
   }
@@ -86,7 +86,7 @@ __device__ __forceinline__ void mlp3_fwd_tile(const Mlp3FwdArgs& a, int m, float
                       [=](auto guarded, int row, int col, float y) {
                         if (h1 != nullptr && (!decltype(guarded)::value || row < rows_here)) h1[row * HID + col] = y;
                       },
-                      [&] { wide_prefetch(w2, HID, ring); }, mask1, rows_here == TB);
+                      [&] { wide_prefetch(w2, HID, ring); }, mask1, rows_here == TB, (rows_here + 31) / 32);
   TR(2);
   mlp3_fwd_tail<ACT, MT, RG, NT>(a, m, Xs, ring, h2, mask2, row0, rows_here);
   TR(5);
