@@ -198,7 +198,9 @@ typedef struct MobodyHyper {
   int32_t q_weighted, scale_q;
 } MobodyHyper;
 
-/* floats of scratch the training calls need */
+/* floats of scratch the training calls need.  The SAME workspace has to be handed to mobody_actor_forward and the
+ * following mobody_actor_backward: it carries pi(s), the Q values, the saved activations and the ReLU sign words
+ * between the two calls (the data-parallel caller all-reduces `stats` in between). */
 int64_t mobody_train_workspace(const MobodyTrainDims* d);
 
 /* Critic loss + gradients (A.2): grad_q (MobodyMlpLayout(S+A,1,2) layout) and loss_out[0] = L_Q of
