@@ -365,3 +365,40 @@ def test_dara_penalty_type_end_to_end(dev):
     pol.train(src, tar, 64, None, None)
     assert torch.equal(src.reward, r1) and len(calls) == 5000
     assert all(np.isfinite(x) for x in pol.losses())
+
+
+def test_graph_mode_across_refresh_boundaries(dev, monkeypatch):
+    """Graph replay is dropped on the eager refresh steps (mobody.py:441: every REFRESH_EVERY steps) and re-captured
+    afterwards with the host-side Adam step counts; the fake buffer keeps growing and nothing goes non-finite."""
+    from mobody_amd import synthetic
+    from mobody_amd.algo import utils
+    from mobody_amd.algo.call_algo import call_algo
+    from mobody_amd.algo.offline_offline import mobody as mob
+    from mobody_amd.algo.dynamics.mobody_module import MOBODYModule
+    from mobody_amd.algo.dynamics.mobody_dynamics import MOBODYEnsembleDynamics
+    from mobody_amd.algo.mb_utils.terminal_funs import get_termination_fn
+    monkeypatch.setattr(mob, "REFRESH_EVERY", 40)
+    monkeypatch.setattr(mob, "REFRESH_SRC", 600, raising=False)
+    S, A, task, bs = 17, 6, "walker2d-medium-v2", 64
+    torch.manual_seed(2)
+    cfg = gu.policy_cfg(S, A, rng="device", seed=4, graph=1, penalty_type="none")
+    pol = call_algo("mobody", cfg, 3, dev)
+    src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=4000, rng="device", seed=1), 4000, task, 0)
+    tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=2500, rng="device", seed=2), 2500, task, 1)
+    model = synthetic.alive_dynamics(MOBODYModule(S, A, 256, 7, 5, device=dev, config=cfg), task)
+    pol.dynamics = MOBODYEnsembleDynamics(cfg, model, None, None, get_termination_fn(task), penalty_coef=0.1, rng="device", seed=9)
+    sizes, captured = [], 0
+    for step in range(1, 131):
+        had = pol._graph is not None
+        pol.train(src, tar, bs, None, None)
+        if (step - 1) % 40 == 0:
+            assert pol._graph is None                      # eager refresh step
+            sizes.append(int(pol.fake_replay_buffer.size))
+        elif not had and pol._graph is not None:
+            captured += 1
+    torch.cuda.synchronize()
+    assert captured == 4 and len(sizes) == 4 and all(b > a for a, b in zip(sizes, sizes[1:])), (captured, sizes)
+    assert pol.total_it == 130 and pol.q_optimizer.t == 130 and pol.policy_optimizer.t == 130
+    assert pol._ctr.tolist()[1:] == [130, 130]
+    assert all(np.isfinite(v) for v in pol.losses())
+    assert torch.isfinite(pol.policy.blob).all() and torch.isfinite(pol.q_funcs.blob).all()
