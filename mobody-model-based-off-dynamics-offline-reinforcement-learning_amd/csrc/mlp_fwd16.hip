@@ -120,6 +120,8 @@ static int launch16_t(const Mlp3FwdArgs& a, int members, hipStream_t stream) {
 
 // Rows per workgroup (in 16-row tiles) such that the grid is about one workgroup per CU.
 int pick_mt16(long long row_members) {
+  static const int forced = [] { const char* e = getenv("MOBODY_CORE16_MT"); return e ? atoi(e) : 0; }();   // tuning aid
+  if (forced > 0) return forced;
   const long long need = cdiv(row_members, 256LL * 16);
   for (int mt : {2, 4, 5, 6, 8})
     if (mt >= need) return mt;
