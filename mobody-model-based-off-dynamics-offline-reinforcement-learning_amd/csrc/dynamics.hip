@@ -154,19 +154,24 @@ __device__ __forceinline__ bool term_predicate(int task, const float* n, int S) 
   }
 }
 
-// one thread per row; rows are contiguous [S]-float segments so a wave streams 64*S floats per member
-__global__ __launch_bounds__(256) void k_dyn_sample(DynSampleArgs a) {
-  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+// One thread per (row, state dim) element, a workgroup owns rpb = 256 / S whole rows: the member means, the noise and
+// next_obs are read / written at consecutive addresses by consecutive lanes.  (The first version used one thread per
+// row walking its S floats: every store instruction scattered 64 dwords over 64 rows and WRITE_SIZE showed 10x the
+// algorithmic bytes.)  The per-row sums over d (penalty) go through LDS and are added in increasing d by one thread
+// per (row, member): same order as a serial loop, no atomics.
+__global__ __launch_bounds__(256) void k_dyn_sample(DynSampleArgs a, int rpb) {
+  __shared__ float s_nxt[256];
+  __shared__ float s_t2[256 * NENS];
+  __shared__ float s_sq[64 * NENS];
   const int S = a.S;
-  int e_sel;
-  if (a.elite_idx) e_sel = a.elite_idx[b];
-  else e_sel = a.elites[rng_index_at(a.seed, STREAM_ELITE, a.call, (uint64_t)b, (uint32_t)a.n_elites)];
-  float sq[NENS];
-#pragma unroll
-  for (int e = 0; e < NENS; ++e) sq[e] = 0.f;
-  float* nxt = a.next_obs + b * S;
-  for (int d = 0; d < S; ++d) {
+  const int tid = threadIdx.x;
+  const int r = tid / S, d = tid - r * S;
+  const long long row0 = (long long)blockIdx.x * rpb;
+  const long long b = row0 + r;
+  if (r < rpb && b < a.B) {
+    int e_sel;
+    if (a.elite_idx) e_sel = a.elite_idx[b];
+    else e_sel = a.elites[rng_index_at(a.seed, STREAM_ELITE, a.call, (uint64_t)b, (uint32_t)a.n_elites)];
     float mval[NENS], avg = 0.f, msel = 0.f;
 #pragma unroll
     for (int e = 0; e < NENS; ++e) {
@@ -177,20 +182,33 @@ __global__ __launch_bounds__(256) void k_dyn_sample(DynSampleArgs a) {
     avg *= (1.f / NENS);
     float var = 0.f;
 #pragma unroll
-    for (int e = 0; e < NENS; ++e) { const float t = mval[e] - avg; var += t * t; if (d < S - 1) sq[e] += t * t; }
+    for (int e = 0; e < NENS; ++e) { const float t = mval[e] - avg; var += t * t; s_t2[tid * NENS + e] = t * t; }
     const float sd = sqrtf(var * (1.f / (NENS - 1)));                      // torch.std: unbiased (:218)
     float eps;
     if (a.noise) eps = a.noise[((long long)e_sel * a.B + b) * S + d];
     else eps = rng_normal_at(a.seed, STREAM_NOISE, a.call, (uint64_t)b * S + d);
-    nxt[d] = msel + eps * sd;                                             // :220-226
+    const float v = msel + eps * sd;                                       // :220-226
+    a.next_obs[b * S + d] = v;
+    s_nxt[tid] = v;
   }
-  float pmax = 0.f;
+  __syncthreads();
+  for (int t = tid; t < rpb * NENS; t += 256) {                            // (row, member): sum over d < S-1, in order
+    const int rr = t / NENS, e = t - rr * NENS;
+    float sq = 0.f;
+    for (int dd = 0; dd < S - 1; ++dd) sq += s_t2[(rr * S + dd) * NENS + e];
+    s_sq[t] = sq;
+  }
+  __syncthreads();
+  if (tid < rpb && row0 + tid < a.B) {
+    const long long bb = row0 + tid;
+    float pmax = 0.f;
 #pragma unroll
-  for (int e = 0; e < NENS; ++e) pmax = fmaxf(pmax, sq[e]);
-  a.penalty[b] = sqrtf(pmax);                                             // :246-249 (last state dim dropped)
-  bool done = term_predicate(a.task, nxt, S);
-  if (a.alive && !a.alive[b]) done = true;
-  a.terminal[b] = done ? 1 : 0;
+    for (int e = 0; e < NENS; ++e) pmax = fmaxf(pmax, s_sq[tid * NENS + e]);
+    a.penalty[bb] = sqrtf(pmax);                                           // :246-249 (last state dim dropped)
+    bool done = term_predicate(a.task, s_nxt + tid * S, S);
+    if (a.alive && !a.alive[bb]) done = true;
+    a.terminal[bb] = done ? 1 : 0;
+  }
 }
 
 struct DynFinalArgs {
@@ -286,7 +304,8 @@ extern "C" int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, co
   for (int k = 0; k < NENS; ++k) sa.elites[k] = (elites && k < n_elites) ? elites[k] : 0;
   sa.n_elites = n_elites; sa.seed = seed; sa.call = call; sa.B = B; sa.S = S; sa.task = task;
   sa.next_obs = next_obs; sa.penalty = penalty; sa.terminal = terminal;
-  hipLaunchKernelGGL(k_dyn_sample, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, sa);
+  const int rpb = 256 / S < 64 ? 256 / S : 64;         // whole rows per workgroup (S <= 256 is checked by the layout)
+  hipLaunchKernelGGL(k_dyn_sample, dim3((unsigned)cdiv(B, rpb)), dim3(256), 0, st, sa, rpb);
   MB_LAUNCH_OK("k_dyn_sample");
 
   // reward head on [s, a, s'] shared by the 7 members  (mobody_dynamics.py:235)
