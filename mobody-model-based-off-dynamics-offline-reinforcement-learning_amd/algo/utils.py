@@ -72,6 +72,11 @@ class ReplayBuffer(object):
                  terminals=self._to_dev(done, 1))
         self.add_batch(b)
 
+    def add_batch_sep(self, s, a, ns, r, d):
+        """utils.py:94-125: add_batch with the five arrays passed separately (how train_mobody.py:594,633 fills the
+        buffers from the datasets); same single-wrap ring arithmetic."""
+        self.add_batch(dict(obss=s, actions=a, next_obss=ns, rewards=r, terminals=d))
+
     def add_batch(self, batch, keep=None):
         """Bulk ring append (utils.py:43-92).  `batch is None` is a no-op like the reference
         (rollout_length == 0).  `keep` optionally selects rows on the device (fused filter)."""

@@ -66,3 +66,21 @@ def test_ring_append_with_filter_and_concat_gather(dev):
     for k in range(5):
         want = np.concatenate([buf[k].cpu().numpy()[i1], b2[k].cpu().numpy()[i2]], 0)
         assert (out[k].cpu().numpy() == want).all()
+
+
+def test_replay_buffer_mirror_add_batch_sep_equals_add_batch(dev):
+    """ReplayBuffer.add_batch_sep (utils.py:94-125, the driver's dataset fill) == add_batch on the same rows, incl. the wrap."""
+    from mobody_amd.algo import utils
+    rng = np.random.default_rng(3)
+    S, A, cap = 5, 2, 50
+    a, b = utils.ReplayBuffer(S, A, dev, max_size=cap), utils.ReplayBuffer(S, A, dev, max_size=cap)
+    for M in (30, 35, 7):
+        rows = (rng.standard_normal((M, S)).astype(np.float32), rng.standard_normal((M, A)).astype(np.float32),
+                rng.standard_normal((M, S)).astype(np.float32), rng.standard_normal((M, 1)).astype(np.float32),
+                (rng.uniform(size=(M, 1)) > 0.7).astype(np.float32))
+        a.add_batch_sep(*rows)
+        b.add_batch(dict(obss=rows[0], actions=rows[1], next_obss=rows[2], rewards=rows[3], terminals=rows[4]))
+        assert (a.ptr, a.size) == (b.ptr, b.size)
+    assert (a.ptr, a.size) == (22, 50)                       # 30 -> 15 after the wrap of 35 -> 22
+    for x, y in zip(a._fields(), b._fields()):
+        assert torch.equal(x, y)
