@@ -84,3 +84,42 @@ def test_replay_buffer_mirror_add_batch_sep_equals_add_batch(dev):
     assert (a.ptr, a.size) == (22, 50)                       # 30 -> 15 after the wrap of 35 -> 22
     for x, y in zip(a._fields(), b._fields()):
         assert torch.equal(x, y)
+
+
+def test_ring_append_random_sequences_vs_reference_arithmetic(dev):
+    """Random append sequences (sizes up to the capacity, random keep masks, hits of the exact-wrap cases) against a
+    NumPy replay of add_batch's single-wrap slice arithmetic (utils.py:43-92) on the kept rows."""
+    from mobody_amd import ops
+    rng = np.random.default_rng(11)
+    S, A = 3, 2
+    for case in range(25):
+        cap = int(rng.integers(5, 200))
+        buf = tuple(torch.zeros(cap, n, device=dev) for n in (S, A, S, 1, 1))
+        ps = torch.zeros(2, dtype=torch.int64, device=dev)
+        ref = [np.zeros((cap, n), np.float32) for n in (S, A, S, 1, 1)]
+        ptr = size = 0
+        for step in range(6):
+            M = int(rng.choice([1, cap - ptr if cap > ptr else 1, cap, int(rng.integers(1, cap + 1))]))
+            rows = [rng.standard_normal((M, n)).astype(np.float32) for n in (S, A, S, 1)]
+            term = (rng.uniform(size=(M, 1)) > 0.6).astype(np.uint8)
+            keep = (rng.uniform(size=M) > 0.35).astype(np.uint8) if step % 2 else None
+            td = lambda x: torch.from_numpy(x).to(dev).contiguous()
+            ops.ring_append(buf, cap, ps, S, A, td(rows[0]), td(rows[1]), td(rows[2]), td(rows[3]), td(term),
+                            None if keep is None else td(keep))
+            sel = np.ones(M, bool) if keep is None else keep.astype(bool)
+            kept = [r[sel] for r in rows] + [1.0 - term[sel].astype(np.float32)]
+            K = int(sel.sum())
+            if K:                                                   # the reference's slice arithmetic on the kept rows
+                end = min(ptr + K, cap)
+                used = end - ptr
+                for dst, src in zip(ref, kept):
+                    dst[ptr:end] = src[:used]
+                ptr = end % cap
+                size = min(size + used, cap)
+                if ptr == 0:
+                    for dst, src in zip(ref, kept):
+                        dst[0:K - used] = src[used:]
+                    ptr = K - used
+            assert ps.cpu().tolist() == [ptr, size], (case, step, cap, M, K)
+            for t, want in zip(buf, ref):
+                assert (t.cpu().numpy() == want).all(), (case, step)
