@@ -213,6 +213,15 @@ int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const flo
  * [N] bootstrap values supplied by the caller, V(s') in the advantage variant (update_q_functions_1, :210-229;
  * actor_blob / qtarg_blob / next_state may then be NULL). */
 
+/* Single-GPU form of mobody_critic_step + mobody_adam_polyak (mobody.py:540-552): the gradient reduction applies the
+ * Adam step (1-based t, or a device word t_dev) and the Polyak update of qtarg_blob (tau from `h`) itself, so the
+ * gradient blob is never written -- one launch and one gradient round trip fewer.  Bit-identical to the two calls. */
+int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, float* q_blob,
+                         float* q_blob_T, float* qtarg_blob, const float* state, const float* action,
+                         const float* next_state, const float* reward, const float* not_done, const float* q_next,
+                         float* m, float* v, int64_t t, const int64_t* t_dev, float lr, float* loss_out,
+                         float* workspace, void* stream);
+
 /* Actor phase, part 1: forwards + the two batch statistics stats[0]=sum|min Q(s,pi(s))|,
  * stats[1]=sum|min Q(s_t,a_t)| over LOCAL rows (all-reduce them across ranks before part 2). */
 int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* q_blob,
@@ -224,6 +233,12 @@ int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const 
                           const float* action, const float* stats, const float* v_true, float* grad_actor,
                           float* loss_out, float* workspace, void* stream);
 /* v_true: NULL -> BC weights exp(3*q_b/mean|q_b|); [Nt] V(s_true) -> exp(3*(q_b - V)) (config['advantage'], :255-256). */
+
+/* Single-GPU form of mobody_actor_backward + mobody_adam_polyak (mobody.py:554-578), as mobody_critic_update. */
+int mobody_actor_update(const MobodyTrainDims* d, const MobodyHyper* h, float* actor_blob, float* actor_blob_T,
+                        const float* q_blob, const float* q_blob_T, const float* state, const float* action,
+                        const float* stats, const float* v_true, float* m, float* v, int64_t t, const int64_t* t_dev,
+                        float lr, float* loss_out, float* workspace, void* stream);
 
 /* Expectile loss of the V function (update_v_function, mobody.py:231-242): adv = min(qt[0],qt[1]) - v;
  * dz3[N][16] column 0 = dL_V/dV (1/N_global scaling), loss_out[0] = local share of L_V; lossp_ws: ceil(N/256) floats. */

@@ -200,6 +200,9 @@ class MOBODY(object):
         self.use_graph = int(config.get("graph", 0))
         self._graph, self._graph_key = None, None
         self._force_segments = False           # test hook: replay the data-parallel segments even with one rank
+        # one GPU: the gradient reduction applies Adam/Polyak itself (mobody_critic_update / mobody_actor_update);
+        # config['fused_update']=0 keeps the separate gradient blobs + optimizer launches (what N > 1 ranks use)
+        self.fused_update = int(config.get("fused_update", 1))
         self._ctr = torch.zeros(3, dtype=torch.int64, device=self.device)      # [rng call, critic t, actor t]
 
     # ------------------------------------------------------------------ acting
@@ -378,6 +381,14 @@ class MOBODY(object):
             self.q_optimizer.step_dev(c[1:2], target=self.target_q_funcs, tau=self.tau)
             self.actor_stats(b, N, Nt, Ng, Ntg)
 
+        def fused_step():
+            ops.counter_add(c)
+            ops.gather_batch_rng([rb._fields() for rb in bufs], cnts, seeds, [0] * len(bufs), c[0:1],
+                                 [rb.ptr_size[1:2] for rb in bufs], S, A, b)
+            self.critic_update(b, N, Nt, t_dev=c[1:2])
+            self.actor_stats(b, N, Nt, N, Nt)
+            self.actor_update(b, N, Nt, t_dev=c[2:3])
+
         def actor():
             self.actor_grad(b, N, Nt, Ng, Ntg)
 
@@ -385,6 +396,8 @@ class MOBODY(object):
             self.policy_optimizer.step_dev(c[2:3])
 
         if not segmented:
+            if self.fused_update:
+                return [fused_step]
             return [lambda: (critic(), critic_apply_actor_stats(), actor(), actor_apply())]
         return [critic, critic_apply_actor_stats, actor, actor_apply]
 
@@ -484,7 +497,16 @@ class MOBODY(object):
         """critic step -> Adam+Polyak -> actor forward -> (stats all-reduce) -> actor backward -> Adam
         (exchange protocol: mobody_amd/dp.py)."""
         d = torch.distributed
-        dp.dp_update(self, b, N, Nt, d if d.is_available() and d.is_initialized() else None)
+        dist = d if d.is_available() and d.is_initialized() else None
+        if self.fused_update and dp.world_size(dist) == 1:
+            if self.config["advantage"]:                                     # V update first (mobody.py:533-537)
+                self.value_grad(b, N, Nt, N, Nt)
+                self.value_apply()
+            self.critic_update(b, N, Nt)
+            self.actor_stats(b, N, Nt, N, Nt)
+            self.actor_update(b, N, Nt)
+        else:
+            dp.dp_update(self, b, N, Nt, dist)
 
     # ---- engine interface of dp.dp_update (every method only enqueues HIP kernels) ----
     def comm_device(self):
@@ -521,6 +543,29 @@ class MOBODY(object):
             q_next = ops.mlp3_forward(self.v_func.blob, self.S, 1, 1, b[2]).view(N)
         ops.critic_step(dims, hyp, self.policy.blob, self.q_funcs.blob, self.q_funcs.blob_T, self.target_q_funcs.blob,
                         b, self.q_optimizer.grad, self._loss[0:1], self._ws, q_next=q_next)
+
+    def critic_update(self, b, N, Nt, t_dev=None):
+        """critic_grad + critic_apply in the fused single-GPU form (same arithmetic, no gradient blob)."""
+        dims, hyp = self._dims(N, Nt, N, Nt)
+        q_next = None
+        if self.config["advantage"]:
+            q_next = ops.mlp3_forward(self.v_func.blob, self.S, 1, 1, b[2]).view(N)
+        o = self.q_optimizer
+        if t_dev is None:
+            o.t += 1
+        ops.critic_update(dims, hyp, self.policy.blob, self.q_funcs.blob, self.q_funcs.blob_T, self.target_q_funcs.blob, b,
+                          o.m, o.v, o.t, o.lr, self._loss[0:1], self._ws, q_next=q_next, t_dev=t_dev)
+
+    def actor_update(self, b, N, Nt, t_dev=None):
+        dims, hyp = self._dims(N, Nt, N, Nt)
+        v_true = None
+        if self.config["advantage"] and Nt > 0:
+            v_true = ops.mlp3_forward(self.v_func.blob, self.S, 1, 1, b[0][:Nt]).view(Nt)
+        o = self.policy_optimizer
+        if t_dev is None:
+            o.t += 1
+        ops.actor_update(dims, hyp, self.policy.blob, self.policy.blob_T, self.q_funcs.blob, self.q_funcs.blob_T, b[0], b[1],
+                         self._stats, o.m, o.v, o.t, o.lr, self._loss[1:3], self._ws, v_true=v_true, t_dev=t_dev)
 
     def critic_grad_buffer(self):
         return self.q_optimizer.grad

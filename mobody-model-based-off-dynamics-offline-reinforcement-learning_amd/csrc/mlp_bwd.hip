@@ -429,7 +429,8 @@ __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
       s += v0; s += v1; s += v2; s += v3;
     }
     for (; k < a.nsplit; ++k) s += a.slabs[(long long)k * a.slab_stride + j];
-    a.grad[j] = s;
+    if (a.grad != nullptr) a.grad[j] = s;
+    if (a.adam.on) adam_element(a.adam, a.L, j, s);
     return;
   }
   // ---- bias part: wave index -> (member, bias element) ----
@@ -468,7 +469,8 @@ __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if (lane == 0) {
     const long long dst = (long long)m * a.L.member_floats + (off < HID ? a.L.b1 + off : off < 2 * HID ? a.L.b2 + (off - HID) : a.L.b3 + (off - 2 * HID));
-    a.grad[dst] = s;
+    if (a.grad != nullptr) a.grad[dst] = s;
+    if (a.adam.on) adam_element(a.adam, a.L, dst, s);
   }
 }
 

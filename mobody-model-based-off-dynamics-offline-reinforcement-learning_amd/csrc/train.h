@@ -1,6 +1,9 @@
 // Argument blocks shared by the training translation units (mlp_bwd.hip, train.hip).
 #pragma once
+#include <math.h>
+
 #include "common.h"
+#include "tile.h"
 
 namespace mobody {
 
@@ -78,6 +81,64 @@ struct WgradArgs {
 };
 int launch_wgrad(WgradArgs a, hipStream_t st);
 
+// Same op forms as torch's single-tensor Adam: exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2);
+// denom = sqrt(v)/sqrt(bc2) + eps; p.addcdiv_(m, denom, -lr/bc1).  The scalar constants are formed in double
+// on the host and rounded to fp32 once, as torch does when it multiplies a fp32 tensor by a Python float.
+struct AdamConsts { float w1, b2, w2, step_size, bc2_sqrt, eps, tau, one_minus_tau, gscale; };
+
+// Destination of parameter entry (member-local offset o) inside the member's T blob, or -1 (biases, padding rows).
+__device__ __forceinline__ long long t_blob_index(const MobodyMlpLayout& L, long long o) {
+  if (o < L.b1) {                                   // W1 (wide storage): W1T[n][k] row major, ld = Np1t
+    const long long g = o >> 2;
+    const int k = (int)(g / HID) * 4 + (int)(o & 3), n = (int)(g % HID);
+    return L.w1t + (long long)n * L.Np1t + k;
+  }
+  if (o >= L.w2 && o < L.b2) {                      // W2 (wide): W2T[n][k] wide
+    const long long oo = o - L.w2, g = oo >> 2;
+    const int k = (int)(g / HID) * 4 + (int)(oo & 3), n = (int)(g % HID);
+    return L.w2t + wide_idx(n, k);
+  }
+  if (o >= L.w3 && o < L.b3) {                      // W3 (narrow [256][Np3]): W3T[n3][k] wide
+    const long long oo = o - L.w3;
+    const int k = (int)(oo / L.Np3), n3 = (int)(oo % L.Np3);
+    return L.w3t + wide_idx(n3, k);
+  }
+  return -1;
+}
+
+// Parameter blobs an optimizer step works on.  Used by k_adam (gradient read from a blob) and by k_grad_reduce (the
+// single-GPU fused form: the element's gradient is the slab / partial sum it has just formed -- one launch and one
+// gradient round trip through HBM fewer per network and step).
+struct AdamTarget {
+  float *p, *m, *v, *target, *blob_T;       // target / blob_T may be null
+  AdamConsts c;
+  const long long* t_dev;                   // device step count (graph replay) or null
+  float lr;
+  int on;                                   // k_grad_reduce only: 0 = just write the gradient
+};
+
+__device__ __forceinline__ void adam_element(const AdamTarget& a, const MobodyMlpLayout& L, long long j, float g) {
+  AdamConsts c = a.c;
+  if (a.t_dev != nullptr) {                         // graph replay: the step count lives in device memory
+    const double t = (double)a.t_dev[0];
+    c.step_size = (float)((double)a.lr / (1.0 - pow(0.9, t)));
+    c.bc2_sqrt = (float)sqrt(1.0 - pow(0.999, t));
+  }
+  const float gj = g * c.gscale;
+  const float m0 = a.m[j];
+  const float mj = m0 + c.w1 * (gj - m0);
+  const float vj = c.b2 * a.v[j] + c.w2 * (gj * gj);
+  a.m[j] = mj; a.v[j] = vj;
+  const float pj = a.p[j] - c.step_size * (mj / (sqrtf(vj) / c.bc2_sqrt + c.eps));
+  a.p[j] = pj;
+  if (a.target != nullptr) a.target[j] = c.tau * pj + c.one_minus_tau * a.target[j];      // update_target :183-187
+  if (a.blob_T != nullptr) {                        // keep the transposes the backward kernels stream in sync
+    const int mem = (int)(j / L.member_floats);
+    const long long ti = t_blob_index(L, j - (long long)mem * L.member_floats);
+    if (ti >= 0) a.blob_T[(long long)mem * L.t_member_floats + ti] = pj;
+  }
+}
+
 // Final reduction of per-workgroup loss partials, done by one extra workgroup of k_grad_reduce (saves a launch).
 //   kind 1 (critic): out[0] = scale * sum parts[k]
 //   kind 2 (actor):  parts = pairs (sum -min q, sum w*(pi-a)^2);  bc = s1/ntg_a;
@@ -92,8 +153,9 @@ struct GradReduceArgs {
   MobodyMlpLayout L;
   const float* slabs; long long slab_stride; int nsplit;
   const float* dbp; int ntiles;
-  float* grad;
+  float* grad;          // may be null when `adam.on` (nobody reads the gradient blob on one GPU)
   LossFinal loss;       // kind 0: none
+  AdamTarget adam;      // on = 0: none
 };
 int launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);
 

@@ -143,54 +143,10 @@ __global__ __launch_bounds__(256) void k_sum_scale(const float* parts, int n, fl
 // ------------------------------------------------------------------------------------------------
 // Adam + Polyak, transposes
 // ------------------------------------------------------------------------------------------------
-// Same op forms as torch's single-tensor Adam: exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2);
-// denom = sqrt(v)/sqrt(bc2) + eps; p.addcdiv_(m, denom, -lr/bc1).  The scalar constants are formed in double
-// on the host and rounded to fp32 once, as torch does when it multiplies a fp32 tensor by a Python float.
-struct AdamConsts { float w1, b2, w2, step_size, bc2_sqrt, eps, tau, one_minus_tau, gscale; };
-
-// Destination of parameter entry (member-local offset o) inside the member's T blob, or -1 (biases, padding rows).
-__device__ __forceinline__ long long t_blob_index(const MobodyMlpLayout& L, long long o) {
-  if (o < L.b1) {                                   // W1 (wide storage): W1T[n][k] row major, ld = Np1t
-    const long long g = o >> 2;
-    const int k = (int)(g / HID) * 4 + (int)(o & 3), n = (int)(g % HID);
-    return L.w1t + (long long)n * L.Np1t + k;
-  }
-  if (o >= L.w2 && o < L.b2) {                      // W2 (wide): W2T[n][k] wide
-    const long long oo = o - L.w2, g = oo >> 2;
-    const int k = (int)(g / HID) * 4 + (int)(oo & 3), n = (int)(g % HID);
-    return L.w2t + wide_idx(n, k);
-  }
-  if (o >= L.w3 && o < L.b3) {                      // W3 (narrow [256][Np3]): W3T[n3][k] wide
-    const long long oo = o - L.w3;
-    const int k = (int)(oo / L.Np3), n3 = (int)(oo % L.Np3);
-    return L.w3t + wide_idx(n3, k);
-  }
-  return -1;
-}
-
-__global__ __launch_bounds__(256) void k_adam(float* p, const float* g, float* m, float* v, float* target, long long n,
-                                              AdamConsts c, const long long* t_dev, float lr, MobodyMlpLayout L,
-                                              float* blob_T) {
+__global__ __launch_bounds__(256) void k_adam(AdamTarget a, const float* g, long long n, MobodyMlpLayout L) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  if (t_dev != nullptr) {                         // graph replay: the step count lives in device memory
-    const double t = (double)t_dev[0];
-    c.step_size = (float)((double)lr / (1.0 - pow(0.9, t)));
-    c.bc2_sqrt = (float)sqrt(1.0 - pow(0.999, t));
-  }
-  const float gj = g[j] * c.gscale;
-  const float m0 = m[j];
-  const float mj = m0 + c.w1 * (gj - m0);
-  const float vj = c.b2 * v[j] + c.w2 * (gj * gj);
-  m[j] = mj; v[j] = vj;
-  const float pj = p[j] - c.step_size * (mj / (sqrtf(vj) / c.bc2_sqrt + c.eps));
-  p[j] = pj;
-  if (target != nullptr) target[j] = c.tau * pj + c.one_minus_tau * target[j];      // update_target :183-187
-  if (blob_T != nullptr) {                          // keep the transposes the backward kernels stream in sync
-    const int mem = (int)(j / L.member_floats);
-    const long long ti = t_blob_index(L, j - (long long)mem * L.member_floats);
-    if (ti >= 0) blob_T[(long long)mem * L.t_member_floats + ti] = pj;
-  }
+  adam_element(a, L, j, g[j]);
 }
 
 // W1 and W2 (and W3T, W2T of the T blob) are 256 columns wide and stored K-interleaved (tile.h wide_idx);
@@ -238,7 +194,7 @@ static Mlp3FwdArgs fwd_args(const float* blob, const MobodyMlpLayout& L, const f
 // weight gradients of one packed MLP: one merged split-K launch + the deterministic reduction
 static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h1, const float* h2, const float* dz3,
                         const float* dz2, const float* dz1, long long rows, const TrainWs& w, float* grad,
-                        const LossFinal& loss, hipStream_t st) {
+                        const LossFinal& loss, const AdamTarget& adam, hipStream_t st) {
   WgradArgs g{};
   const int nsplit = L.members == 1 ? w.nsplit_a : w.nsplit_q;
   const long long slab_stride = (L.total_floats + 3) & ~3LL;
@@ -253,7 +209,7 @@ static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h
   g.job[2] = WgradJob{dz3, rows * L.Np3, L.Np3, L.Np3, h2, hs, HID, HID, L.w3, L.Np3, L.Np3, HID, 1, 0, 0, 0};
   int rc = launch_wgrad(g, st);
   if (rc) return rc;
-  GradReduceArgs r{L, w.slabs, slab_stride, nsplit, w.dbp, w.ntiles, grad, loss};
+  GradReduceArgs r{L, w.slabs, slab_stride, nsplit, w.dbp, w.ntiles, grad, loss, adam};
   return launch_grad_reduce(r, st);
 }
 
@@ -278,14 +234,16 @@ extern "C" int64_t mobody_train_workspace(const MobodyTrainDims* d) {
   return w.total;
 }
 
-extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
-                                  const float* q_blob, const float* q_blob_T, const float* qtarg_blob,
-                                  const float* state, const float* action, const float* next_state,
-                                  const float* reward, const float* not_done, const float* q_next, float* grad_q,
-                                  float* loss_out, float* workspace, void* stream) {
+static AdamTarget adam_target(float* blob, float* blob_T, float* m, float* v, float* target, int64_t t, const int64_t* t_dev,
+                              float lr, float tau, float grad_scale);
+
+static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* q_blob,
+                       const float* q_blob_T, const float* qtarg_blob, const float* state, const float* action,
+                       const float* next_state, const float* reward, const float* not_done, const float* q_next,
+                       float* grad_q, const AdamTarget& adam, float* loss_out, float* workspace, void* stream) {
   int rc = check_dims(d, "mobody_critic_step");
   if (rc) return rc;
-  MB_REQUIRE(h && q_blob && q_blob_T && state && action && reward && not_done && grad_q && loss_out && workspace,
+  MB_REQUIRE(h && q_blob && q_blob_T && state && action && reward && not_done && (grad_q || adam.on) && loss_out && workspace,
              "mobody_critic_step: null pointer");
   MB_REQUIRE(q_next || (actor_blob && qtarg_blob && next_state), "mobody_critic_step: need q_next or actor/target/next_state");
   TrainWs w;
@@ -313,7 +271,29 @@ extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h
   if (rc) return rc;
   LossFinal lf{};                                  // q_loss = mse(q1,y)+mse(q2,y), local share of the global mean
   lf.kind = 1; lf.nparts = 2 * w.ntiles; lf.scale = invNg; lf.parts = w.lossp; lf.out = loss_out;
-  return weight_grads(w.Lq, w.xq, w.h1q, w.h2q, w.dz3q, w.dz2, w.dz1, N, w, grad_q, lf, st);
+  return weight_grads(w.Lq, w.xq, w.h1q, w.h2q, w.dz3q, w.dz2, w.dz1, N, w, grad_q, lf, adam, st);
+}
+
+extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
+                                  const float* q_blob, const float* q_blob_T, const float* qtarg_blob,
+                                  const float* state, const float* action, const float* next_state,
+                                  const float* reward, const float* not_done, const float* q_next, float* grad_q,
+                                  float* loss_out, float* workspace, void* stream) {
+  MB_REQUIRE(grad_q, "mobody_critic_step: grad_q is null");
+  return critic_impl(d, h, actor_blob, q_blob, q_blob_T, qtarg_blob, state, action, next_state, reward, not_done, q_next,
+                     grad_q, AdamTarget{}, loss_out, workspace, stream);
+}
+
+extern "C" int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, float* q_blob,
+                                    float* q_blob_T, float* qtarg_blob, const float* state, const float* action,
+                                    const float* next_state, const float* reward, const float* not_done,
+                                    const float* q_next, float* m, float* v, int64_t t, const int64_t* t_dev, float lr,
+                                    float* loss_out, float* workspace, void* stream) {
+  MB_REQUIRE(h && q_blob && q_blob_T && qtarg_blob && m && v, "mobody_critic_update: null pointer");
+  MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_critic_update: step t must be >= 1");
+  return critic_impl(d, h, actor_blob, q_blob, q_blob_T, qtarg_blob, state, action, next_state, reward, not_done, q_next,
+                     nullptr, adam_target(q_blob, q_blob_T, m, v, qtarg_blob, t, t_dev, lr, h->tau, 1.f), loss_out,
+                     workspace, stream);
 }
 
 extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
@@ -340,14 +320,14 @@ extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper*
   return 0;
 }
 
-extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
-                                     const float* actor_blob_T, const float* q_blob, const float* q_blob_T,
-                                     const float* state, const float* action, const float* stats, const float* v_true,
-                                     float* grad_actor, float* loss_out, float* workspace, void* stream) {
+static int actor_backward_impl(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
+                               const float* actor_blob_T, const float* q_blob, const float* q_blob_T, const float* state,
+                               const float* action, const float* stats, const float* v_true, float* grad_actor,
+                               const AdamTarget& adam, float* loss_out, float* workspace, void* stream) {
   int rc = check_dims(d, "mobody_actor_backward");
   if (rc) return rc;
-  MB_REQUIRE(h && actor_blob && actor_blob_T && q_blob && q_blob_T && state && action && stats && grad_actor && loss_out &&
-                 workspace, "mobody_actor_backward: null pointer");
+  MB_REQUIRE(h && actor_blob && actor_blob_T && q_blob && q_blob_T && state && action && stats && (grad_actor || adam.on) &&
+                 loss_out && workspace, "mobody_actor_backward: null pointer");
   TrainWs w;
   rc = carve(*d, workspace, w);
   if (rc) return rc;
@@ -372,7 +352,27 @@ extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper
   LossFinal lf{};                                  // loss_out[0] = p_w*mean(-q) + bc_coef*L_BC, [1] = L_BC (local shares)
   lf.kind = 2; lf.nparts = w.ntiles; lf.scale_q = h->scale_q; lf.weight = h->weight; lf.bc_coef = h->bc_coef;
   lf.ng = (float)ra.Ng; lf.ntg_a = (float)ra.Ntg * (float)ra.A; lf.parts = w.lossp; lf.stats = stats; lf.out = loss_out;
-  return weight_grads(w.La, w.xa, w.h1a, w.h2a, w.dz3a, w.dz2, w.dz1, N, w, grad_actor, lf, st);
+  return weight_grads(w.La, w.xa, w.h1a, w.h2a, w.dz3a, w.dz2, w.dz1, N, w, grad_actor, lf, adam, st);
+}
+
+extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
+                                     const float* actor_blob_T, const float* q_blob, const float* q_blob_T,
+                                     const float* state, const float* action, const float* stats, const float* v_true,
+                                     float* grad_actor, float* loss_out, float* workspace, void* stream) {
+  MB_REQUIRE(grad_actor, "mobody_actor_backward: grad_actor is null");
+  return actor_backward_impl(d, h, actor_blob, actor_blob_T, q_blob, q_blob_T, state, action, stats, v_true, grad_actor,
+                             AdamTarget{}, loss_out, workspace, stream);
+}
+
+extern "C" int mobody_actor_update(const MobodyTrainDims* d, const MobodyHyper* h, float* actor_blob, float* actor_blob_T,
+                                   const float* q_blob, const float* q_blob_T, const float* state, const float* action,
+                                   const float* stats, const float* v_true, float* m, float* v, int64_t t,
+                                   const int64_t* t_dev, float lr, float* loss_out, float* workspace, void* stream) {
+  MB_REQUIRE(actor_blob && actor_blob_T && m && v, "mobody_actor_update: null pointer");
+  MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_actor_update: step t must be >= 1");
+  return actor_backward_impl(d, h, actor_blob, actor_blob_T, q_blob, q_blob_T, state, action, stats, v_true, nullptr,
+                             adam_target(actor_blob, actor_blob_T, m, v, nullptr, t, t_dev, lr, -1.f, 1.f), loss_out,
+                             workspace, stream);
 }
 
 extern "C" int mobody_mlp_transpose(int in_dim, int out_dim, int members, const float* blob, float* blob_T, void* stream) {
@@ -385,6 +385,21 @@ extern "C" int mobody_mlp_transpose(int in_dim, int out_dim, int members, const 
   return 0;
 }
 
+// torch.optim.Adam scalar bookkeeping in double, as the reference's host code does
+static AdamTarget adam_target(float* blob, float* blob_T, float* m, float* v, float* target, int64_t t, const int64_t* t_dev,
+                              float lr, float tau, float grad_scale) {
+  const double tt = t_dev ? 1.0 : (double)t;
+  const double bc1 = 1.0 - pow(0.9, tt), bc2 = 1.0 - pow(0.999, tt);
+  AdamTarget a{};
+  a.p = blob; a.m = m; a.v = v; a.blob_T = blob_T;
+  a.target = (target != nullptr && tau >= 0.f) ? target : nullptr;
+  a.c.w1 = (float)(1.0 - 0.9); a.c.b2 = (float)0.999; a.c.w2 = (float)(1.0 - 0.999);
+  a.c.step_size = (float)((double)lr / bc1); a.c.bc2_sqrt = (float)sqrt(bc2); a.c.eps = 1e-8f;
+  a.c.tau = tau; a.c.one_minus_tau = (float)(1.0 - (double)tau); a.c.gscale = grad_scale;
+  a.t_dev = (const long long*)t_dev; a.lr = lr; a.on = 1;
+  return a;
+}
+
 static int adam_impl(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad, float* m,
                      float* v, float* target, int64_t t, const int64_t* t_dev, float lr, float tau, float grad_scale,
                      void* stream) {
@@ -393,17 +408,9 @@ static int adam_impl(int in_dim, int out_dim, int members, float* blob, float* b
   if (rc) return rc;
   MB_REQUIRE(blob && grad && m && v, "mobody_adam_polyak: null pointer");
   MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_adam_polyak: step t must be >= 1");
-  // torch.optim.Adam scalar bookkeeping in double, as the reference's host code does
-  const double tt = t_dev ? 1.0 : (double)t;
-  const double bc1 = 1.0 - pow(0.9, tt), bc2 = 1.0 - pow(0.999, tt);
-  AdamConsts c;
-  c.w1 = (float)(1.0 - 0.9); c.b2 = (float)0.999; c.w2 = (float)(1.0 - 0.999);
-  c.step_size = (float)((double)lr / bc1); c.bc2_sqrt = (float)sqrt(bc2); c.eps = 1e-8f;
-  c.tau = tau; c.one_minus_tau = (float)(1.0 - (double)tau); c.gscale = grad_scale;
-  float* tgt = (target != nullptr && tau >= 0.f) ? target : nullptr;
+  const AdamTarget a = adam_target(blob, blob_T, m, v, target, t, t_dev, lr, tau, grad_scale);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(k_adam, dim3((unsigned)cdiv(L.total_floats, 256)), dim3(256), 0, st, blob, grad, m, v, tgt,
-                     (long long)L.total_floats, c, (const long long*)t_dev, lr, L, blob_T);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)cdiv(L.total_floats, 256)), dim3(256), 0, st, a, grad, (long long)L.total_floats, L);
   MB_LAUNCH_OK("k_adam");
   return 0;       // (W1T's zero padding columns k >= Kp1 are written once by mobody_mlp_transpose and never change)
 }

@@ -139,6 +139,24 @@ def actor_backward(dims, hyp, actor_blob, actor_blob_T, q_blob, q_blob_T, state,
                                        ptr(loss_out), ptr(ws), cur_stream()), "mobody_actor_backward")
 
 
+def critic_update(dims, hyp, actor_blob, q_blob, q_blob_T, qtarg_blob, batch, m, v, t, lr, loss_out, ws, q_next=None,
+                  t_dev=None):
+    """critic_step + Adam + Polyak in the fused single-GPU form (t: host step count, or t_dev: device int64[1])."""
+    s, a, s2, r, nd = batch
+    check(load().mobody_critic_update(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(q_blob), ptr(q_blob_T),
+                                      ptr(qtarg_blob), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(q_next), ptr(m),
+                                      ptr(v), int(t), ptr(t_dev), float(lr), ptr(loss_out), ptr(ws), cur_stream()),
+          "mobody_critic_update")
+
+
+def actor_update(dims, hyp, actor_blob, actor_blob_T, q_blob, q_blob_T, state, action, stats, m, v, t, lr, loss_out, ws,
+                 v_true=None, t_dev=None):
+    check(load().mobody_actor_update(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(actor_blob_T), ptr(q_blob),
+                                     ptr(q_blob_T), ptr(state), ptr(action), ptr(stats), ptr(v_true), ptr(m), ptr(v),
+                                     int(t), ptr(t_dev), float(lr), ptr(loss_out), ptr(ws), cur_stream()),
+          "mobody_actor_update")
+
+
 def value_loss_grad(qt, v, n_global):
     """qt [2,N] target twin-Q(s,a), v [N] -> (dz3[N,16], loss[1]) of the expectile V loss."""
     N = v.numel()

@@ -207,3 +207,26 @@ def test_adam_polyak_kernel(dev):
     close(packing.wide_unpack(pt[L.w3t:L.w3t + 256 * L.Np3], L.Np3), W3.t(), rtol=0, atol=0)
     W1 = packing.wide_unpack(p[L.w1:L.w1 + L.Kp1 * 256], L.Kp1)
     close(pt[L.w1t:L.w1t + 256 * L.Np1t].view(256, L.Np1t)[:, :L.Kp1], W1.t(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("S,A,N,Nt", [(17, 6, 640, 512), (45, 24, 130, 65)])
+def test_fused_update_is_bit_identical_to_step_plus_adam(S, A, N, Nt, dev):
+    """mobody_critic_update / mobody_actor_update (Adam + Polyak inside the gradient reduction) vs the separate
+    gradient + mobody_adam_polyak calls: same parameters, moments, target and transposed blobs, bit for bit."""
+    from mobody_amd import ops
+    cfg = gu.policy_cfg(S, A)
+    pa, pq, _ = gu.policy_params(31, S, A)
+    batch = gu.gi.batch(8, N, S, A)
+    ref, fus = Engine(S, A, pa, pq, dev), Engine(S, A, pa, pq, dev)
+    b = [torch.as_tensor(x, dtype=torch.float32).to(dev).contiguous() for x in batch]
+    dims, hyp = ops.train_dims(S, A, N, Nt), ops.hyper(cfg)
+    ws = ops.train_workspace(dims, dev)
+    for step in (1, 2, 3):
+        ref.step(batch, Nt, cfg)
+        ops.critic_update(dims, hyp, fus.actor, fus.q, fus.q_T, fus.qt, b, fus.mq, fus.vq, step, cfg["critic_lr"], fus.loss[0:1], ws)
+        ops.actor_forward(dims, hyp, fus.actor, fus.q, b[0], b[1], fus.stats, ws)
+        ops.actor_update(dims, hyp, fus.actor, fus.actor_T, fus.q, fus.q_T, b[0], b[1], fus.stats, fus.ma, fus.va, step,
+                         cfg["actor_lr"], fus.loss[1:3], ws)
+        torch.cuda.synchronize()
+        for name in ("q", "q_T", "qt", "mq", "vq", "actor", "actor_T", "ma", "va", "loss"):
+            assert torch.equal(getattr(ref, name), getattr(fus, name)), (step, name)
