@@ -208,8 +208,11 @@ int64_t mobody_train_workspace(const MobodyTrainDims* d);
 int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* q_blob,
                        const float* q_blob_T, const float* qtarg_blob, const float* state, const float* action,
                        const float* next_state, const float* reward, const float* not_done, const float* q_next,
-                       float* grad_q, float* loss_out, float* workspace, void* stream);
-/* q_next: NULL -> min target-Q(s', pi(s')) is computed here (update_q_functions, mobody.py:189-208); non-NULL ->
+                       float* grad_q, float* loss_out, float* workspace, int policy_forward, void* stream);
+/* policy_forward != 0 (needs q_next == NULL): the target-Q launch also evaluates pi(s) with its saves for the coming
+ * mobody_actor_forward(..., policy_ready = 1) on the same workspace -- the actor does not change in between, and
+ * the merged launch fills the chip better than the two it replaces.
+ * q_next: NULL -> min target-Q(s', pi(s')) is computed here (update_q_functions, mobody.py:189-208); non-NULL ->
  * [N] bootstrap values supplied by the caller, V(s') in the advantage variant (update_q_functions_1, :210-229;
  * actor_blob / qtarg_blob / next_state may then be NULL). */
 
@@ -220,12 +223,14 @@ int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper* h, const f
                          float* q_blob_T, float* qtarg_blob, const float* state, const float* action,
                          const float* next_state, const float* reward, const float* not_done, const float* q_next,
                          float* m, float* v, int64_t t, const int64_t* t_dev, float lr, float* loss_out,
-                         float* workspace, void* stream);
+                         float* workspace, int policy_forward, void* stream);
 
 /* Actor phase, part 1: forwards + the two batch statistics stats[0]=sum|min Q(s,pi(s))|,
  * stats[1]=sum|min Q(s_t,a_t)| over LOCAL rows (all-reduce them across ranks before part 2). */
 int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* q_blob,
-                         const float* state, const float* action, float* stats, float* workspace, void* stream);
+                         const float* state, const float* action, float* stats, float* workspace, int policy_ready,
+                         void* stream);
+/* policy_ready != 0: pi(s) and its saves are already in the workspace (mobody_critic_step(..., policy_forward = 1)). */
 
 /* Actor phase, part 2: grad_actor (MobodyMlpLayout(S,A,1)) and loss_out[0]=L_pi, [1]=L_BC (local share). */
 int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,

@@ -76,14 +76,14 @@ PROTOTYPES = {
                                      vp]),
     "mobody_train_workspace": (i64, [C.POINTER(MobodyTrainDims)]),
     "mobody_critic_step": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp,
-                                     vp, vp, vp, vp, vp, vp, vp]),
+                                     vp, vp, vp, vp, vp, vp, C.c_int, vp]),
     "mobody_critic_update": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp,
-                                       vp, vp, vp, vp, vp, i64, vp, f32, vp, vp, vp]),
+                                       vp, vp, vp, vp, vp, i64, vp, f32, vp, vp, C.c_int, vp]),
     "mobody_actor_update": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, vp, i64, vp, f32, vp, vp, vp]),
     "mobody_value_loss_grad": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp]),
     "mobody_actor_forward": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp,
-                                       vp]),
+                                       C.c_int, vp]),
     "mobody_actor_backward": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp,
                                         vp, vp, vp, vp, vp, vp]),
     "mobody_adam_polyak": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp]),

@@ -542,7 +542,13 @@ class MOBODY(object):
         if self.config["advantage"]:                                        # update_q_functions_1: y = r + nd*gamma*V(s')
             q_next = ops.mlp3_forward(self.v_func.blob, self.S, 1, 1, b[2]).view(N)
         ops.critic_step(dims, hyp, self.policy.blob, self.q_funcs.blob, self.q_funcs.blob_T, self.target_q_funcs.blob,
-                        b, self.q_optimizer.grad, self._loss[0:1], self._ws, q_next=q_next)
+                        b, self.q_optimizer.grad, self._loss[0:1], self._ws, q_next=q_next,
+                        policy_forward=self._policy_rides_along())
+
+    def _policy_rides_along(self):
+        """pi(s) of the actor phase is evaluated in the critic phase's target-Q launch (the actor does not change in
+        between); not in the advantage variant, whose critic call has no target-Q launch."""
+        return not self.config["advantage"]
 
     def critic_update(self, b, N, Nt, t_dev=None):
         """critic_grad + critic_apply in the fused single-GPU form (same arithmetic, no gradient blob)."""
@@ -554,7 +560,8 @@ class MOBODY(object):
         if t_dev is None:
             o.t += 1
         ops.critic_update(dims, hyp, self.policy.blob, self.q_funcs.blob, self.q_funcs.blob_T, self.target_q_funcs.blob, b,
-                          o.m, o.v, o.t, o.lr, self._loss[0:1], self._ws, q_next=q_next, t_dev=t_dev)
+                          o.m, o.v, o.t, o.lr, self._loss[0:1], self._ws, q_next=q_next, t_dev=t_dev,
+                          policy_forward=self._policy_rides_along())
 
     def actor_update(self, b, N, Nt, t_dev=None):
         dims, hyp = self._dims(N, Nt, N, Nt)
@@ -575,7 +582,8 @@ class MOBODY(object):
 
     def actor_stats(self, b, N, Nt, Ng, Ntg):
         dims, hyp = self._dims(N, Nt, Ng, Ntg)
-        ops.actor_forward(dims, hyp, self.policy.blob, self.q_funcs.blob, b[0], b[1], self._stats, self._ws)
+        ops.actor_forward(dims, hyp, self.policy.blob, self.q_funcs.blob, b[0], b[1], self._stats, self._ws,
+                          policy_ready=self._policy_rides_along())
 
     def stats_buffer(self):
         return self._stats

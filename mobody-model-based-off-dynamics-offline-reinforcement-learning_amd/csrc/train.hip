@@ -18,6 +18,7 @@ namespace mobody {
 // ------------------------------------------------------------------------------------------------
 struct TrainWs {
   uint32_t *mq1, *mq2, *ma1, *ma2;      // ReLU sign words of the twin-Q / actor hidden layers
+  float *pin;            // pi(s') of the critic phase (pi holds pi(s) for the actor phase)
   float *pi, *qt, *q, *qb, *xq, *h1q, *h2q, *xa, *h1a, *h2a, *dz3q, *dz2, *dz1, *dz3a, *dxa, *bcw, *dbp, *slabs, *lossp;
   long long total;
   int nsplit_q, nsplit_a, ntiles, tile_rows;
@@ -33,6 +34,7 @@ static int carve(const MobodyTrainDims& d, float* base, TrainWs& w) {
   long long off = 0;
   auto take = [&](long long n) { float* p = base ? base + off : nullptr; off += (n + 3) & ~3LL; return p; };
   w.pi = take(N * d.A);
+  w.pin = take(N * d.A);
   w.qt = take(2 * N);
   w.q = take(2 * N);
   w.qb = take(2 * Nt);
@@ -240,7 +242,8 @@ static AdamTarget adam_target(float* blob, float* blob_T, float* m, float* v, fl
 static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* q_blob,
                        const float* q_blob_T, const float* qtarg_blob, const float* state, const float* action,
                        const float* next_state, const float* reward, const float* not_done, const float* q_next,
-                       float* grad_q, const AdamTarget& adam, float* loss_out, float* workspace, void* stream) {
+                       float* grad_q, const AdamTarget& adam, float* loss_out, float* workspace, int policy_forward,
+                       void* stream) {
   int rc = check_dims(d, "mobody_critic_step");
   if (rc) return rc;
   MB_REQUIRE(h && q_blob && q_blob_T && state && action && reward && not_done && (grad_q || adam.on) && loss_out && workspace,
@@ -255,9 +258,15 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
   // online twin-Q(s, a), activations kept for the backward (:196), together with a' = pi(s') (:191) in one launch
   const Mlp3FwdArgs fq = fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q, w.mq1, w.mq2);
   if (q_next == nullptr) {
-    rc = launch_mlp3_fwd_pair(fq, 2, fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pi, 1, h->max_action, nullptr, nullptr, nullptr), 1, st);
-    // target twin-Q(s', a')                                                    (:192)
-    if (!rc) rc = launch_mlp3_fwd(fwd_args(qtarg_blob, w.Lq, next_state, S, w.pi, A, N, w.qt, 0, 1.f, nullptr, nullptr, nullptr), 2, ACT_RELU, st);
+    rc = launch_mlp3_fwd_pair(fq, 2, fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pin, 1, h->max_action, nullptr, nullptr, nullptr), 1, st);
+    // target twin-Q(s', a') (:192) -- and, when the caller asks for it, pi(s) of the coming actor phase in the same
+    // launch: the actor is not updated in between, and a twin-Q launch alone is 2.5 workgroups per CU where the
+    // merged one is 3.75 (the actor phase then opens with Q(s_t,a_t) alone: exactly 2 per CU)
+    const Mlp3FwdArgs ft = fwd_args(qtarg_blob, w.Lq, next_state, S, w.pin, A, N, w.qt, 0, 1.f, nullptr, nullptr, nullptr);
+    if (!rc && policy_forward)
+      rc = launch_mlp3_fwd_pair(ft, 2, fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2), 1, st);
+    else if (!rc)
+      rc = launch_mlp3_fwd(ft, 2, ACT_RELU, st);
   } else {
     rc = launch_mlp3_fwd(fq, 2, ACT_RELU, st);     // q_next = V(s') supplied by the caller (update_q_functions_1, :210-229)
   }
@@ -278,27 +287,27 @@ extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h
                                   const float* q_blob, const float* q_blob_T, const float* qtarg_blob,
                                   const float* state, const float* action, const float* next_state,
                                   const float* reward, const float* not_done, const float* q_next, float* grad_q,
-                                  float* loss_out, float* workspace, void* stream) {
+                                  float* loss_out, float* workspace, int policy_forward, void* stream) {
   MB_REQUIRE(grad_q, "mobody_critic_step: grad_q is null");
   return critic_impl(d, h, actor_blob, q_blob, q_blob_T, qtarg_blob, state, action, next_state, reward, not_done, q_next,
-                     grad_q, AdamTarget{}, loss_out, workspace, stream);
+                     grad_q, AdamTarget{}, loss_out, workspace, policy_forward, stream);
 }
 
 extern "C" int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, float* q_blob,
                                     float* q_blob_T, float* qtarg_blob, const float* state, const float* action,
                                     const float* next_state, const float* reward, const float* not_done,
                                     const float* q_next, float* m, float* v, int64_t t, const int64_t* t_dev, float lr,
-                                    float* loss_out, float* workspace, void* stream) {
+                                    float* loss_out, float* workspace, int policy_forward, void* stream) {
   MB_REQUIRE(h && q_blob && q_blob_T && qtarg_blob && m && v, "mobody_critic_update: null pointer");
   MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_critic_update: step t must be >= 1");
   return critic_impl(d, h, actor_blob, q_blob, q_blob_T, qtarg_blob, state, action, next_state, reward, not_done, q_next,
                      nullptr, adam_target(q_blob, q_blob_T, m, v, qtarg_blob, t, t_dev, lr, h->tau, 1.f), loss_out,
-                     workspace, stream);
+                     workspace, policy_forward, stream);
 }
 
 extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
                                     const float* q_blob, const float* state, const float* action, float* stats,
-                                    float* workspace, void* stream) {
+                                    float* workspace, int policy_ready, void* stream) {
   int rc = check_dims(d, "mobody_actor_forward");
   if (rc) return rc;
   MB_REQUIRE(h && actor_blob && q_blob && state && action && stats && workspace, "mobody_actor_forward: null pointer");
@@ -309,9 +318,12 @@ extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper*
   const long long N = d->N, Nt = d->Nt;
   const int S = d->S, A = d->A;
   // Q(s_true, a_true) for the BC weights (:251) and pi(s) on the whole mixed batch (its first Nt rows are
-  // pi(s_true), mobody.py:249,315) in one launch
-  rc = launch_mlp3_fwd_pair(fwd_args(q_blob, w.Lq, state, S, action, A, Nt, w.qb, 0, 1.f, nullptr, nullptr, nullptr), 2,
-                            fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2), 1, st);
+  // pi(s_true), mobody.py:249,315) in one launch -- unless the critic call already left pi(s) in the workspace
+  const Mlp3FwdArgs fb = fwd_args(q_blob, w.Lq, state, S, action, A, Nt, w.qb, 0, 1.f, nullptr, nullptr, nullptr);
+  if (policy_ready)
+    rc = launch_mlp3_fwd(fb, 2, ACT_RELU, st);
+  else
+    rc = launch_mlp3_fwd_pair(fb, 2, fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2), 1, st);
   // Q(s, pi(s)) with the freshly updated critic (:316); dQ/da through the frozen net needs only the ReLU signs
   if (!rc) rc = launch_mlp3_fwd(fwd_args(q_blob, w.Lq, state, S, w.pi, A, N, w.q, 0, 1.f, nullptr, nullptr, nullptr, w.mq1, w.mq2), 2, ACT_RELU, st);
   if (rc) return rc;

@@ -120,16 +120,18 @@ def mlp_transpose(blob, in_dim, out_dim, members):
     return bt
 
 
-def critic_step(dims, hyp, actor_blob, q_blob, q_blob_T, qtarg_blob, batch, grad_q, loss_out, ws, q_next=None):
+def critic_step(dims, hyp, actor_blob, q_blob, q_blob_T, qtarg_blob, batch, grad_q, loss_out, ws, q_next=None,
+                policy_forward=False):
     s, a, s2, r, nd = batch
     check(load().mobody_critic_step(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(q_blob), ptr(q_blob_T),
                                     ptr(qtarg_blob), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(q_next), ptr(grad_q),
-                                    ptr(loss_out), ptr(ws), cur_stream()), "mobody_critic_step")
+                                    ptr(loss_out), ptr(ws), int(bool(policy_forward)), cur_stream()), "mobody_critic_step")
 
 
-def actor_forward(dims, hyp, actor_blob, q_blob, state, action, stats, ws):
+def actor_forward(dims, hyp, actor_blob, q_blob, state, action, stats, ws, policy_ready=False):
     check(load().mobody_actor_forward(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(q_blob), ptr(state),
-                                      ptr(action), ptr(stats), ptr(ws), cur_stream()), "mobody_actor_forward")
+                                      ptr(action), ptr(stats), ptr(ws), int(bool(policy_ready)), cur_stream()),
+          "mobody_actor_forward")
 
 
 def actor_backward(dims, hyp, actor_blob, actor_blob_T, q_blob, q_blob_T, state, action, stats, grad_actor, loss_out,
@@ -140,12 +142,13 @@ def actor_backward(dims, hyp, actor_blob, actor_blob_T, q_blob, q_blob_T, state,
 
 
 def critic_update(dims, hyp, actor_blob, q_blob, q_blob_T, qtarg_blob, batch, m, v, t, lr, loss_out, ws, q_next=None,
-                  t_dev=None):
+                  t_dev=None, policy_forward=False):
     """critic_step + Adam + Polyak in the fused single-GPU form (t: host step count, or t_dev: device int64[1])."""
     s, a, s2, r, nd = batch
     check(load().mobody_critic_update(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(q_blob), ptr(q_blob_T),
                                       ptr(qtarg_blob), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(q_next), ptr(m),
-                                      ptr(v), int(t), ptr(t_dev), float(lr), ptr(loss_out), ptr(ws), cur_stream()),
+                                      ptr(v), int(t), ptr(t_dev), float(lr), ptr(loss_out), ptr(ws),
+                                      int(bool(policy_forward)), cur_stream()),
           "mobody_critic_update")
 
 

@@ -230,3 +230,24 @@ def test_fused_update_is_bit_identical_to_step_plus_adam(S, A, N, Nt, dev):
         torch.cuda.synchronize()
         for name in ("q", "q_T", "qt", "mq", "vq", "actor", "actor_T", "ma", "va", "loss"):
             assert torch.equal(getattr(ref, name), getattr(fus, name)), (step, name)
+
+
+def test_policy_forward_riding_with_the_target_q_launch_is_bit_identical(dev):
+    """mobody_critic_step(policy_forward=1) + mobody_actor_forward(policy_ready=1) == the default placement of pi(s)."""
+    from mobody_amd import ops
+    S, A, N, Nt = 17, 6, 333, 200
+    cfg = gu.policy_cfg(S, A)
+    pa, pq, _ = gu.policy_params(41, S, A)
+    b = [torch.as_tensor(x, dtype=torch.float32).to(dev).contiguous() for x in gu.gi.batch(9, N, S, A)]
+    dims, hyp = ops.train_dims(S, A, N, Nt), ops.hyper(cfg)
+    outs = []
+    for ride in (False, True):
+        e = Engine(S, A, pa, pq, dev)
+        ws = ops.train_workspace(dims, dev)
+        ops.critic_step(dims, hyp, e.actor, e.q, e.q_T, e.qt, b, e.gq, e.loss[0:1], ws, policy_forward=ride)
+        ops.actor_forward(dims, hyp, e.actor, e.q, b[0], b[1], e.stats, ws, policy_ready=ride)
+        ops.actor_backward(dims, hyp, e.actor, e.actor_T, e.q, e.q_T, b[0], b[1], e.stats, e.ga, e.loss[1:3], ws)
+        torch.cuda.synchronize()
+        outs.append((e.gq.clone(), e.ga.clone(), e.loss.clone(), e.stats.clone()))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
