@@ -5,7 +5,8 @@
 //                  (zs1-3, za1-2, transition1-3) chained through one LDS image;
 //                  grid = (ceil(B/64), 7) so even B = 4096 fills the chip (448 WGs).
 //   k_dyn_sample   ensemble std, Gaussian sample of the elite member, pairwise-diff
-//                  penalty, termination predicate                   mobody_dynamics.py:218-256,
+//                  penalty, termination predicate (one thread per (row, state dim), whole rows per
+//                  workgroup)                                       mobody_dynamics.py:218-256,
 //                                                                    terminal_funs.py:10-113
 //   reward head    generic fused MLP forward (Swish) on [s,a,s']     mobody_module.py:295-302
 //   k_dyn_finalize reward = mean_e r_mu - coef*penalty               mobody_dynamics.py:236,261-263

@@ -1,14 +1,17 @@
 // Backward kernels of the 3-layer ReLU MLP (actor / twin-Q), fp32 MFMA.
 //
-//   k_mlp3_bwd   per (64-row tile, member): dz3 -> dz2 = (dz3 W3^T) * [h2>0] -> dz1 = (dz2 W2^T) * [h1>0]
-//                (-> dx = dz1 W1^T for the frozen-Q pass of the actor update), plus the bias-gradient
-//                partial sums of the tile.  W^T blobs are streamed as MFMA B operands exactly like the
-//                forward weights.                                   (autograd of mobody.py:35-48)
+//   k_mlp3_bwd   per (32-row tile, member): dz3 (read, or formed in the prologue from the row-wise inputs: TD error,
+//                -p_w dmin(Q), actor d(pre-tanh)) -> dz2 = (dz3 W3^T) * [h2>0] -> dz1 = (dz2 W2^T) * [h1>0]
+//                (-> dx = dz1 W1^T for the frozen-Q pass of the actor update), plus the bias-gradient and loss
+//                partial sums of the tile.  Masks come from the forward's sign words (or the saved activations);
+//                W^T blobs are streamed as MFMA B operands exactly like the forward weights.
+//                                                                    (autograd of mobody.py:35-48)
 //   k_wgrad      dW[k][n] = sum_rows A[row][k] * dZ[row][n]: rows are the contraction index, both
 //                operands are read straight from global memory in MFMA fragment order (a wave
 //                instruction = two full 128-byte lines); split-K over row slices, the four waves of a
 //                workgroup reduce through LDS and write one deterministic partial slab.
-//   k_grad_reduce slabs + bias partials -> gradient blob (deterministic, no atomics).
+//   k_grad_reduce slabs + bias partials -> gradient blob (deterministic, no atomics); on one GPU it applies the
+//                Adam / Polyak step to each element it has just reduced, and one extra workgroup finishes the losses.
 //
 // Roofline: k_mlp3_bwd and k_wgrad are MFMA-f32 bound (2*256*256 FLOP per row and layer against
 // ~2 KB of activations per row); k_grad_reduce is HBM/L2 streaming.

@@ -1,8 +1,8 @@
-// Fused 3-layer MLP forward: one workgroup = 64 rows x one member, all three GEMMs on
-// fp32 MFMA with the activations resident in LDS (never written to HBM unless the
-// backward pass asks for them).  Roofline: MFMA f32 (2*(Kp1+256+Np3)*256 FLOP per row
-// against (in+out)*4 bytes per row -> AI > 1000 F/B); weights (<= 340 KB per member)
-// stream from L2.
+// Fused 3-layer MLP forward: one workgroup = one 32-row tile (64 with MOBODY_TILE_ROWS=64) x one member, all three
+// GEMMs on fp32 MFMA with the activations resident in LDS (written to HBM only when the backward pass asks for
+// them: x / h1 / h2 for the weight gradients, 32 B/row of ReLU sign words for the masks).  k_mlp3_fwd2 runs two
+// independent networks in one launch.  Roofline: MFMA f32 (2*(Kp1+256+Np3)*256 FLOP per row against (in+out)*4
+// bytes per row -> AI > 1000 F/B); weights (<= 340 KB per member) stream from L2.
 #include <stdlib.h>
 
 #include "common.h"

@@ -1,6 +1,6 @@
 // MOBODY gradient step: critic (twin-Q TD regression) and actor (Q-scaled policy gradient +
-// Q-weighted behaviour cloning), assembled from the fused MLP forward/backward kernels plus the
-// small row-wise kernels below.  Reference: algo/offline_offline/mobody.py:189-208 (critic),
+// Q-weighted behaviour cloning), assembled from the fused MLP forward/backward kernels (which also form the row-wise
+// quantities in their prologues, mlp_bwd.hip) plus the few row-wise kernels below.  Reference: algo/offline_offline/mobody.py:189-208 (critic),
 // :246-276 (bc_loss), :314-345 (update_policy), :540-578 (order of updates), :183-187 (Polyak).
 //
 // Row-wise kernels are HBM-streaming (a few floats per row); the scalar reductions are
