@@ -31,8 +31,7 @@
  *     N_pad == 256 are stored K-interleaved by four, element (k,n) at ((k/4)*256 + n)*4 + k%4, narrow
  *     ones row major); the host-side mirror (mobody_amd/packing.py) packs/unpacks the reference's
  *     state_dict tensors;
- *   - mobody_critic_step / mobody_actor_forward fork one independent launch onto a library-owned side
- *     stream and join it back before returning: from the caller's side everything is ordered on `stream`.
+ *   - every launch of a call is ordered on the caller's `stream`; the library owns no stream of its own.
  */
 #ifndef MOBODY_HIP_H
 #define MOBODY_HIP_H

@@ -17,7 +17,7 @@ import os
 import numpy as np
 import torch
 
-from ... import ops
+from ... import dp, ops
 
 
 class StandardScaler(object):
@@ -83,7 +83,8 @@ class MOBODYEnsembleDynamics(object):
             self._ws = torch.empty(max(need, 1), dtype=torch.float32, device=m.device)
         return ops.dyn_step(m.packed(), m.obs_dim, m.action_dim, self._task_id, obs, action, noise=noise,
                             elite_idx=elite_idx, alive=alive, elites=[int(e) for e in m.elites.tolist()],
-                            seed=self.seed, call=self._calls, penalty_coef=float(self._penalty_coef or 0.0),
+                            seed=(self.seed + dp.rank_salt()) & 0xFFFFFFFF, call=self._calls,
+                            penalty_coef=float(self._penalty_coef or 0.0),
                             use_penalty=bool(use_penalty), use_trg=bool(use_trg), want_mean=want_mean,
                             workspace=self._ws)
 

@@ -80,6 +80,12 @@ class MOBODYModule(object):
     def parameters(self):
         return [v for k, v in self._p.items() if k != "elites"]
 
+    def broadcast_(self, dist, src=0):
+        """Data parallel: adopt rank `src`'s tensors (every rank rolls out with the same model)."""
+        for k in sorted(self._p):
+            dist.broadcast(self._p[k], src)
+        self._blob = None
+
     def to(self, device):
         return self
 

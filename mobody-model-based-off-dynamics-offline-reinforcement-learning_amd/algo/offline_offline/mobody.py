@@ -23,6 +23,7 @@ from .. import utils
 
 REFRESH_EVERY = 5000        # mobody.py:441
 REFRESH_SRC, REFRESH_TAR = 50000, 2000    # :442-443
+REFRESH_FROM_SRC_TAR = 100                # target init states of the rollout_from_src branch, :485
 
 
 class _PackedNet(object):
@@ -43,9 +44,15 @@ class _PackedNet(object):
         self.training = True
 
     def load_state_dict(self, sd):
-        self.blob = packing.pack_mlp({k: v for k, v in sd.items()}, self.in_dim, self.out_dim, self.device,
-                                     prefixes=list(self.prefixes))
-        self.blob_T = ops.mlp_transpose(self.blob, self.in_dim, self.out_dim, self.members)
+        packed = packing.pack_mlp({k: v for k, v in sd.items()}, self.in_dim, self.out_dim, self.device,
+                                  prefixes=list(self.prefixes))
+        if getattr(self, "blob", None) is None:
+            self.blob = packed
+            self.blob_T = ops.mlp_transpose(self.blob, self.in_dim, self.out_dim, self.members)
+        else:                                         # in place: captured graphs and Adam hold these pointers
+            self.blob.copy_(packed)
+            ops.mlp_transpose(self.blob, self.in_dim, self.out_dim, self.members, out=self.blob_T)
+        self.version = getattr(self, "version", 0) + 1
 
     def state_dict(self):
         out = {}
@@ -121,9 +128,9 @@ class _Adam(object):
             return
         keys = [f"network.{li}.{wb}" for li in (0, 2, 4) for wb in ("weight", "bias")]
         per = len(keys)
-        for name, dst in (("exp_avg", "m"), ("exp_avg_sq", "v")):
+        for name, dst in (("exp_avg", self.m), ("exp_avg_sq", self.v)):
             members = [{k: st[m * per + j][name] for j, k in enumerate(keys)} for m in range(n.members)]
-            setattr(self, dst, packing.pack_mlp(members, n.in_dim, n.out_dim, n.device))
+            dst.copy_(packing.pack_mlp(members, n.in_dim, n.out_dim, n.device))        # in place (graph pointers)
         self.t = int(float(st[0]["step"]))
 
 
@@ -204,6 +211,37 @@ class MOBODY(object):
         # config['fused_update']=0 keeps the separate gradient blobs + optimizer launches (what N > 1 ranks use)
         self.fused_update = int(config.get("fused_update", 1))
         self._ctr = torch.zeros(3, dtype=torch.int64, device=self.device)      # [rng call, critic t, actor t]
+        self._synced = False                   # data parallel: replicas broadcast from rank 0 before the first step
+        self.classifier_noise_fn = None        # optional hook: n_rows -> (noise_sas[n,2S+A], noise_sa[n,S+A]) (tests)
+
+    # ------------------------------------------------------------------ data-parallel replica hygiene
+    def _seed_for(self, k):
+        """Philox seed of the k-th index stream of this rank (src, tar, fake = 101, 102, 103): the rank is folded
+        in here so that ranks never draw the same rows even when every rank was given the same config seed."""
+        return (self.seed + k + dp.rank_salt()) & 0xFFFFFFFF
+
+    def _opts(self):
+        return (self.q_optimizer, self.policy_optimizer, self.v_optimizer, self.classifier.opt_sa, self.classifier.opt_sas)
+
+    def sync_replicas(self):
+        """world > 1: make this replica identical to rank 0's (weights, transposes, Adam moments and step counts,
+        dynamics model).  The all-reduced gradients are only the gradient of the concatenated batch if every rank
+        evaluates them at the same parameters; nothing else in the step exchanges parameters."""
+        self._synced = True
+        if self._world() == 1:
+            return
+        d = torch.distributed
+        nets = (self.q_funcs, self.target_q_funcs, self.policy, self.v_func, self.classifier.sa_classifier,
+                self.classifier.sas_classifier)
+        steps = torch.tensor([o.t for o in self._opts()], dtype=torch.int64, device=self.device)
+        for t in [x for n in nets for x in (n.blob, n.blob_T)] + [x for o in self._opts() for x in (o.m, o.v)] + [steps]:
+            d.broadcast(t, 0)
+        for o, t in zip(self._opts(), steps.tolist()):
+            o.t = int(t)
+        model = getattr(self.dynamics, "model", None)
+        if model is not None and hasattr(model, "broadcast_"):
+            model.broadcast_(d)
+        self._graph = None
 
     # ------------------------------------------------------------------ acting
     def select_action(self, state, policy, cuda=False):
@@ -220,22 +258,30 @@ class MOBODY(object):
         let tests supply the reference's exact permuted batch and noise."""
         cls = self.classifier
         if rows is None:
-            bufs = [src_replay_buffer]
-            counts = [batch_size]
-            n_tar = batch_size
-            if self.config["penalize_fake"] and self.fake_replay_buffer.size > 0:       # :149-154
-                bufs.append(self.fake_replay_buffer); counts.append(batch_size); n_tar = 2 * batch_size
-            bufs.append(tar_replay_buffer); counts.append(n_tar)
+            # Draw order of the reference: src(bs), tar(bs), then with penalize_fake fake(bs), tar(2bs) (:147-154).
+            # Its labels are always [0]*bs + [1]*bs and randperm runs over 2*bs entries (:161-165), so with
+            # penalize_fake the rows that reach the classifier are src (label 0) and FAKE (label 1); both target draws
+            # only advance the index stream.
+            bufs, counts = [src_replay_buffer, tar_replay_buffer], [batch_size, batch_size]
+            use_fake = bool(self.config["penalize_fake"]) and self.fake_replay_buffer.size > 0
+            if use_fake:
+                bufs += [self.fake_replay_buffer, tar_replay_buffer]; counts += [batch_size, 2 * batch_size]
             N = sum(counts)
             out = (torch.empty(N, self.S, device=self.device), torch.empty(N, self.A, device=self.device),
                    torch.empty(N, self.S, device=self.device), torch.empty(N, 1, device=self.device),
                    torch.empty(N, 1, device=self.device))
             self._gather(bufs, counts, out)
-            s, a, s2 = out[0], out[1], out[2]
-            n_src = N - n_tar
+            if use_fake:                              # rows [src | fake]
+                pick = lambda t: torch.cat([t[:batch_size], t[2 * batch_size:3 * batch_size]], 0).contiguous()
+            else:                                     # rows [src | tar]
+                pick = lambda t: t[:2 * batch_size]
+            s, a, s2 = pick(out[0]), pick(out[1]), pick(out[2])
+            n_src = batch_size
         else:
             s, a, s2 = rows
             n_src = s.shape[0] // 2
+        if noise is None and self.classifier_noise_fn is not None:
+            noise = self.classifier_noise_fn(s.shape[0])
         nz = noise or (None, None)
         (z_sas, x_sas, h1s, h2s), (z_sa, x_sa, h1a, h2a) = cls.logits(s, a, s2, True, nz[0], nz[1], seed=self.seed + 31,
                                                                     save=True)
@@ -312,7 +358,7 @@ class MOBODY(object):
         self.fake_replay_buffer._pull()
         return B * rollout_length
 
-    def _refresh(self, src_rb, tar_rb):
+    def _refresh(self, src_rb, tar_rb, batch_size):
         """Model-rollout refresh of the fake buffer, mobody.py:441-513."""
         cfg = self.config
         s_idx = src_rb.draw_indices(REFRESH_SRC)
@@ -334,9 +380,9 @@ class MOBODY(object):
                                                    rewards=r["reward"], terminals=r["terminal"]), keep=keep)
         if cfg["rollout_from_src"]:                                           # :479-513
             if self.penalty_type != "dara":
-                self.update_classifier(src_rb, tar_rb, cfg.get("batch_size", 128))
+                self.update_classifier(src_rb, tar_rb, batch_size)                 # train()'s batch_size, :481
             s_idx = src_rb.draw_indices(REFRESH_SRC)
-            t_idx = tar_rb.draw_indices(100)
+            t_idx = tar_rb.draw_indices(REFRESH_FROM_SRC_TAR)
             init = ops.gather_batch([src_rb._fields(), tar_rb._fields()], [s_idx, t_idx], self.S, self.A)[0]
             tr, _ = self.rollout(init, cfg["rollout_from_src_length"], use_trg=False)
             if tr is not None and tr["obss"].shape[0] > 0:
@@ -367,9 +413,9 @@ class MOBODY(object):
         N, Nt = ns + nt + nf, ns + nt
         Ng, Ntg = N * world, Nt * world
         c, b = self._ctr, self._batch
-        bufs, cnts, seeds = [src, tar], [ns, nt], [self.seed + 101, self.seed + 102]
+        bufs, cnts, seeds = [src, tar], [ns, nt], [self._seed_for(101), self._seed_for(102)]
         if nf > 0:
-            bufs.append(self.fake_replay_buffer); cnts.append(nf); seeds.append(self.seed + 103)
+            bufs.append(self.fake_replay_buffer); cnts.append(nf); seeds.append(self._seed_for(103))
 
         def critic():
             ops.counter_add(c)
@@ -404,7 +450,16 @@ class MOBODY(object):
     def _graph_step(self, src, tar, batch_size):
         world = self._world()
         segmented = world > 1 or (self._force_segments and torch.distributed.is_initialized())
-        key = (batch_size, id(src), id(tar), src.state.data_ptr(), tar.state.data_ptr(), world, segmented)
+        # every device pointer the captured kernels read or write: a reloaded checkpoint, a re-assigned fake buffer
+        # or a resized minibatch must force a re-capture (replaying against freed tensors corrupts memory silently)
+        fb = self.fake_replay_buffer
+        nets = (self.q_funcs, self.target_q_funcs, self.policy)
+        opts = (self.q_optimizer, self.policy_optimizer)
+        key = (batch_size, id(src), id(tar), src.state.data_ptr(), tar.state.data_ptr(), world, segmented,
+               id(fb), fb.state.data_ptr(), fb.ptr_size.data_ptr(), tuple(t.data_ptr() for t in self._batch),
+               tuple((n.blob.data_ptr(), n.blob_T.data_ptr()) for n in nets),
+               tuple((o.m.data_ptr(), o.v.data_ptr(), o.grad.data_ptr()) for o in opts),
+               None if self._ws is None else self._ws.data_ptr())
         if self._graph is None or self._graph_key != key:
             torch.cuda.synchronize()
             self._ctr[1] = self.q_optimizer.t
@@ -445,16 +500,20 @@ class MOBODY(object):
         cfg = self.config
         self.total_it += 1
         self.src_replay_buffer, self.tar_replay_buffer = src_replay_buffer, tar_replay_buffer
-        if self._batch is not None and self._graph_ok(writer) and self._graph_step(src_replay_buffer, tar_replay_buffer, batch_size):
+        if not self._synced:
+            self.sync_replicas()
+        S, A = self.S, self.A
+        ns, nt = int(cfg["src_ratio"] * batch_size), int(cfg["trg_ratio"] * batch_size)
+        nf = int(cfg["fake_batch_scale"] * batch_size) if cfg["fake_batch_scale"] != 0 else 0
+        N, Nt = ns + nt + nf, ns + nt
+        # graph replay only once the minibatch tensors of THIS batch size exist (an eager step allocates them)
+        if (self._batch is not None and self._batch_key == (N,) and self._graph_ok(writer)
+                and self._graph_step(src_replay_buffer, tar_replay_buffer, batch_size)):
             return
         if self._graph is not None:                       # an eager step (refresh/logging) moves the host-side counts
             self._graph = None
         if self.penalty_type == "dara" and self.total_it == 1:
             self._dara_warmup(src_replay_buffer, tar_replay_buffer, batch_size, writer)
-        S, A = self.S, self.A
-        ns, nt = int(cfg["src_ratio"] * batch_size), int(cfg["trg_ratio"] * batch_size)
-        nf = int(cfg["fake_batch_scale"] * batch_size) if cfg["fake_batch_scale"] != 0 else 0
-        N, Nt = ns + nt + nf, ns + nt
         if self._batch_key != (N,):
             dev = self.device
             self._batch = (torch.empty(N, S, device=dev), torch.empty(N, A, device=dev), torch.empty(N, S, device=dev),
@@ -467,7 +526,7 @@ class MOBODY(object):
             r = self.dynamics.step_device(b[0][:ns], b[1][:ns])
             ops.par_penalty(b[2][:ns], r["next_obs"], b[3][:ns], cfg["penalty_coef"])
         if (self.total_it - 1) % REFRESH_EVERY == 0:
-            self._refresh(src_replay_buffer, tar_replay_buffer)
+            self._refresh(src_replay_buffer, tar_replay_buffer, batch_size)
         if nf > 0:                                                            # :523-529
             self._gather([self.fake_replay_buffer], [nf], tuple(t[Nt:] for t in b))
         self._update(b, N, Nt)
@@ -487,7 +546,8 @@ class MOBODY(object):
                 if rb.size <= 0:
                     raise ValueError("low >= high")               # np.random.randint(0, 0) in the reference (Q11)
                 rb._draws += 1
-            ops.gather_batch_rng([rb._fields() for rb in bufs], counts, [rb.seed for rb in bufs],
+            salt = dp.rank_salt()
+            ops.gather_batch_rng([rb._fields() for rb in bufs], counts, [(rb.seed + salt) & 0xFFFFFFFF for rb in bufs],
                                  [rb._draws for rb in bufs], None, [rb.ptr_size[1:2] for rb in bufs], self.S, self.A, out)
         else:
             idx = [rb.draw_indices(n) for rb, n in zip(bufs, counts)]
@@ -614,6 +674,8 @@ class MOBODY(object):
         torch.save(self.policy_optimizer.state_dict(), filename + "_actor_optimizer")
 
     def load(self, filename):
+        self._graph = None                              # re-capture: the device-side Adam step counts change
+        self._synced = False                            # (ranks loading different files are re-aligned to rank 0)
         ld = lambda s: torch.load(filename + s, map_location="cpu", weights_only=True)
         self.q_funcs.load_state_dict(ld("_critic"))
         self.q_optimizer.load_state_dict(ld("_critic_optimizer"))

@@ -94,12 +94,16 @@ class ReplayBuffer(object):
         d = (d.to(self.device).reshape(-1, 1) != 0).to(torch.uint8).contiguous()
         if keep is not None:
             keep = keep.to(device=self.device).reshape(-1).to(torch.uint8).contiguous()
+        rows = self.state.shape[0]
+        if rows != self.max_size and (rows < self.max_size and self._ptr + M > rows):
+            # storage was replaced by convert_D4RL (rows < max_size): the reference's slice assignment raises here
+            raise RuntimeError(f"add_batch: {M} rows at ptr {self._ptr} overflow the {rows}-row storage adopted by convert_D4RL")
         step = 1 << 20                           # kernel limit per call; also bounds the scan workspace
         for i in range(0, M, step):
             j = min(M, i + step)
             if j - i > self.max_size:
                 raise RuntimeError("add_batch: batch overflows the ring twice (shape mismatch in the reference)")
-            ops.ring_append(self._fields(), self.max_size, self.ptr_size, self.state_dim, self.action_dim, s[i:j],
+            ops.ring_append(self._fields(), min(self.max_size, rows), self.ptr_size, self.state_dim, self.action_dim, s[i:j],
                             a[i:j], ns[i:j], r[i:j], d[i:j], None if keep is None else keep[i:j])
         self._pull()
 
@@ -111,7 +115,8 @@ class ReplayBuffer(object):
         self.reward = self._to_dev(dataset["rewards"], 1)
         term = torch.as_tensor(np.asarray(dataset["terminals"])).reshape(-1, 1).to(torch.float32)
         self.not_done = (1.0 - term).to(self.device).contiguous()
-        self.max_size = max(self.max_size, self.state.shape[0])
+        # the reference keeps max_size and ptr as they were: a later add()/add_batch() that runs past the adopted rows
+        # is a shape error there; here add_batch checks the row count before launching (see _rows_ok)
         self.size = self.state.shape[0]
 
     # ---- reads ----
@@ -123,7 +128,8 @@ class ReplayBuffer(object):
         if self._size <= 0:
             raise ValueError("low >= high")
         self._draws += 1
-        return ops.rng_index(self.seed, 3, self._draws, batch_size, self._size, self.device)
+        from .. import dp
+        return ops.rng_index((self.seed + dp.rank_salt()) & 0xFFFFFFFF, 3, self._draws, batch_size, self._size, self.device)
 
     def sample(self, batch_size):
         idx = self.draw_indices(int(batch_size))

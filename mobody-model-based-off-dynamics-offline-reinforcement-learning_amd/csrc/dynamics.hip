@@ -202,10 +202,13 @@ __global__ __launch_bounds__(256) void k_dyn_sample(DynSampleArgs a, int rpb) {
   __syncthreads();
   if (tid < rpb && row0 + tid < a.B) {
     const long long bb = row0 + tid;
+    // torch.amax propagates NaN (one non-finite member makes every norm of the row NaN); fmaxf would drop it and
+    // the row would pass `penalty <= env_filter` with NaN next_obs, where the reference's comparisons are all False
     float pmax = 0.f;
+    bool bad = false;
 #pragma unroll
-    for (int e = 0; e < NENS; ++e) pmax = fmaxf(pmax, s_sq[tid * NENS + e]);
-    a.penalty[bb] = sqrtf(pmax);                                           // :246-249 (last state dim dropped)
+    for (int e = 0; e < NENS; ++e) { const float q = s_sq[tid * NENS + e]; bad = bad || (q != q); pmax = fmaxf(pmax, q); }
+    a.penalty[bb] = bad ? __builtin_nanf("") : sqrtf(pmax);                // :246-249 (last state dim dropped)
     bool done = term_predicate(a.task, s_nxt + tid * S, S);
     if (a.alive && !a.alive[bb]) done = true;
     a.terminal[bb] = done ? 1 : 0;

@@ -17,6 +17,16 @@ built on the oracle under gloo, world size 2.
 """
 
 
+def rank_salt(dist=None):
+    """Per-rank offset folded into every device-RNG seed (index draws, rollout noise, elite picks): 0 on one process."""
+    if dist is None:
+        import torch
+        dist = torch.distributed
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return 1000003 * dist.get_rank()
+    return 0
+
+
 def world_size(dist):
     return dist.get_world_size() if dist is not None and dist.is_available() and dist.is_initialized() else 1
 

@@ -113,9 +113,10 @@ def train_workspace(dims, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
-def mlp_transpose(blob, in_dim, out_dim, members):
+def mlp_transpose(blob, in_dim, out_dim, members, out=None):
     L = _lib.mlp_layout(in_dim, out_dim, members)
-    bt = torch.empty(L.t_total_floats, dtype=torch.float32, device=blob.device)
+    bt = out if out is not None else torch.empty(L.t_total_floats, dtype=torch.float32, device=blob.device)
+    assert bt.numel() == L.t_total_floats
     check(load().mobody_mlp_transpose(in_dim, out_dim, members, ptr(blob), ptr(bt), cur_stream()), "mobody_mlp_transpose")
     return bt
 

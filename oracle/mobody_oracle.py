@@ -162,11 +162,14 @@ def dyn_step(p, obs, act, eps, elite_idx, task, penalty_coef=0.0, use_penalty=Tr
     """MOBODYEnsembleDynamics.step, mobody_dynamics.py:193-265 (pairwise-diff uncertainty).
 
     eps:[E,B,S] unit normals (the reference draws torch.normal(0,std); explicit here),
-    elite_idx:[B] member ids (the reference draws np.random.choice(elites,B)).
+    elite_idx:[B] member ids, or None to draw np.random.choice(elites,B) from the NumPy global
+    stream exactly where the reference does (:224).
     Returns dict(next_obs[B,S], reward[B,1], terminal bool[B,1], penalty[B,1],
                  raw_reward[B,1], mean[E,B,S]).
     """
     obs, act, eps = T(obs), T(act), T(eps)
+    if elite_idx is None:                     # random_elite_idxs, mobody_module.py:355-357 (NumPy global stream)
+        elite_idx = np.random.choice(np.asarray(p["elites"]) if "elites" in p else np.arange(5), size=obs.shape[0])
     mean, _, _ = dyn_forward(p, obs, act, use_trg)                               # :211-214
     std = torch.std(mean, dim=0, keepdim=True)                                   # :218 unbiased
     samples = mean + eps * std                                                   # :220
@@ -219,11 +222,12 @@ def value_fn(p, s):
 
 
 def rollout(actor_p, dyn_p, init_obs, H, eps_per_step, elite_per_step, task, cfg, use_trg=True,
-            penalty_coef=0.0):
+            penalty_coef=0.0, draws=None):
     """MOBODY.rollout, mobody.py:596-657.
 
     eps_per_step[t]:[E,B_t,S], elite_per_step[t]:[B_t] follow the *compacted* batch
-    of step t (terminated rows are dropped between steps, :635-639).
+    of step t (terminated rows are dropped between steps, :635-639); alternatively `draws`
+    is an iterator yielding (eps, elite_idx) once per executed step.
     Quirk Q1: `use_trg` lands in step()'s `use_penalty` slot (:614), the target
     model is always used.
     """
@@ -234,7 +238,8 @@ def rollout(actor_p, dyn_p, init_obs, H, eps_per_step, elite_per_step, task, cfg
     n_tr, rew_all = 0, []
     for t in range(H):
         act = actor(actor_p, obs, cfg["max_action"]).reshape(-1, cfg["action_dim"])          # :612
-        st = dyn_step(dyn_p, obs, act, eps_per_step[t], elite_per_step[t], task,
+        eps_t, idx_t = next(draws) if draws is not None else (eps_per_step[t], elite_per_step[t])
+        st = dyn_step(dyn_p, obs, act, eps_t, idx_t, task,
                       penalty_coef=penalty_coef, use_penalty=use_trg, use_trg=True)          # :614
         out["obss"].append(obs); out["next_obss"].append(st["next_obs"]); out["actions"].append(act)
         out["rewards"].append(st["reward"]); out["terminals"].append(T(st["terminal"].astype(np.float32)))
@@ -276,6 +281,67 @@ def ring_append_plan(ptr, size, cap, M):
             segs.append((0, used, rest))
         new_ptr = rest
     return segs, new_ptr, new_size
+
+
+class RingBuffer:
+    """ReplayBuffer, algo/utils.py:13-148, reduced to what the path uses: SoA arrays, the single-wrap bulk append
+    (`ring_append_plan`) and `sample` = rows at np.random.randint(0, size, n) (NumPy global stream, :128)."""
+
+    FIELDS = ("state", "action", "next_state", "reward", "not_done")
+
+    def __init__(self, S, A, cap):
+        self.cap, self.ptr, self.size = int(cap), 0, 0
+        self.state, self.action = np.zeros((cap, S), np.float32), np.zeros((cap, A), np.float32)
+        self.next_state = np.zeros((cap, S), np.float32)
+        self.reward, self.not_done = np.zeros((cap, 1), np.float32), np.zeros((cap, 1), np.float32)
+
+    def add_batch(self, b):
+        if b is None:                                                             # :44-45
+            return
+        rows = [np.asarray(b[k], np.float32).reshape(len(b["obss"]), -1) for k in ("obss", "actions", "next_obss", "rewards")]
+        rows.append(1.0 - np.asarray(b["terminals"], np.float32).reshape(-1, 1))  # not_done = 1 - terminals (:73)
+        segs, self.ptr, self.size = ring_append_plan(self.ptr, self.size, self.cap, len(rows[0]))
+        for dst, src, n in segs:
+            for f, r in zip(self.FIELDS, rows):
+                getattr(self, f)[dst:dst + n] = r[src:src + n]
+
+    def sample(self, n):
+        ind = np.random.randint(0, self.size, size=n)
+        return tuple(T(getattr(self, f)[ind]) for f in self.FIELDS)
+
+
+def refresh(actor_p, dyn_p, src, tar, fake, cfg, task, draws, batch_size, sizes=(50000, 2000, 100), penalty_coef=0.0,
+            classifier_update=None, cls_p=None):
+    """The model-rollout refresh inside MOBODY.train, mobody.py:441-513, in the reference's order:
+    sample(src, 50000) -> sample(tar, 2000) -> rollout(src states, src_rollout_length) -> add -> rollout(tar states,
+    trg_rollout_length) -> add -> [use_src_sa_to_get_target_next_state: step(src s, src a), keep penalty < env_filter
+    (STRICT, :466), add] -> [rollout_from_src: one classifier update unless dara (:480-481), sample(src, 50000),
+    sample(tar, 100), rollout(cat, rollout_from_src_length, use_trg=False), rewards += penalty_coef * delta_r, add].
+    `draws` yields (eps[E,B,S], elite_idx[B]) for every dynamics.step call in order."""
+    draws = iter(draws)
+
+    def roll(init, H, use_trg=True):
+        return rollout(actor_p, dyn_p, init, H, None, None, task, cfg, use_trg=use_trg, penalty_coef=penalty_coef,
+                       draws=draws)[0]
+
+    s_init = src.sample(sizes[0])
+    t_init = tar.sample(sizes[1])
+    fake.add_batch(roll(s_init[0], cfg["src_rollout_length"]))
+    fake.add_batch(roll(t_init[0], cfg["trg_rollout_length"]))
+    if cfg["use_src_sa_to_get_target_next_state"]:
+        eps, idx = next(draws)
+        st = dyn_step(dyn_p, s_init[0], s_init[1], eps, idx, task, penalty_coef=penalty_coef)
+        keep = (st["penalty"] < cfg["env_filter"]).squeeze(1)                      # strict '<', :466
+        fake.add_batch(dict(obss=s_init[0][keep], next_obss=st["next_obs"][keep], actions=s_init[1][keep],
+                            rewards=st["reward"][keep], terminals=T(st["terminal"].astype(np.float32))[keep]))
+    if cfg["rollout_from_src"]:
+        if cfg["penalty_type"] != "dara":
+            classifier_update(src, tar, batch_size)
+        s2 = src.sample(sizes[0]); t2 = tar.sample(sizes[2])
+        tr = roll(torch.cat([s2[0], t2[0]], 0), cfg["rollout_from_src_length"], use_trg=False)
+        with torch.no_grad():
+            tr["rewards"] = tr["rewards"] + cfg["penalty_coef"] * dara_delta_r(cls_p, tr["obss"], tr["actions"], tr["next_obss"])
+        fake.add_batch(tr)
 
 
 # --------------------------------------------------------------------------- #

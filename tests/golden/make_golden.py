@@ -379,7 +379,183 @@ def g9():
     save("g9_dara", **out)
 
 
+def g9b():
+    """update_classifier with penalize_fake=1 and a non-empty fake buffer (mobody.py:146-181): the reference draws
+    src(bs), tar(bs), fake(bs), tar(2bs) and -- because its labels stay [0]*bs+[1]*bs and randperm runs over 2*bs
+    entries -- trains on the src rows (label 0) and the FAKE rows (label 1) only."""
+    S, A, bs = 17, 6, 24
+    cfg = policy_cfg(S, A, penalty_type="dara", penalize_fake=1)
+    pol, _, _, _ = make_policy(cfg, 401)
+    pc = {}
+    pc.update({"sa_classifier." + k: v for k, v in gi.mlp_params(701, S + A, 2).items()})
+    pc.update({"sas_classifier." + k: v for k, v in gi.mlp_params(702, 2 * S + A, 2).items()})
+    load_mlp(pol.classifier, pc)
+    log = []
+
+    class LogRB(FixedRB):
+        def __init__(self, rows, name):
+            super().__init__(rows); self.name = name
+
+        def sample(self, n):
+            log.append(f"{self.name}:{n}")
+            return super().sample(n)
+
+    src = LogRB(gi.batch(704, 64, S, A), "src"); tar = LogRB(gi.batch(705, 64, S, A), "tar")
+    pol.fake_replay_buffer = LogRB(gi.batch(706, 64, S, A), "fake")
+    taps = dict(perm=None, noise=[])
+    o_perm, o_randn = torch.randperm, torch.randn_like
+
+    def randperm(n, **k):
+        q = o_perm(n, **k); taps["perm"] = q.numpy().copy(); return q
+
+    def randn_like(x, **k):
+        e = o_randn(x); taps["noise"].append(e.numpy().copy()); return e
+
+    torch.randperm, torch.randn_like = randperm, randn_like
+    try:
+        torch.manual_seed(6)
+        loss_sa, loss_sas = pol.update_classifier(src, tar, bs, None)
+    finally:
+        torch.randperm, torch.randn_like = o_perm, o_randn
+    out = dict(S=S, A=A, bs=bs, seed_sa=701, seed_sas=702, wsum=gi.checksum(pc), perm=taps["perm"],
+               noise_sas=taps["noise"][0], noise_sa=taps["noise"][1], loss_sa=float(loss_sa), loss_sas=float(loss_sas),
+               draw_log=np.array(log))
+    for k, v in pol.classifier.named_parameters():
+        out["cls_g::" + k] = sub(v.grad.numpy()); out["cls_p::" + k] = sub(v.detach().numpy())
+    print("penalize_fake draws", log, "perm len", len(taps["perm"]), "loss", float(loss_sa), float(loss_sas))
+    save("g9_dara_penfake", **out)
+
+
+# -------------------------------------------------------------------------- G11
+class CudaAlias:
+    """Harness-side alias 'cuda' -> cpu for the call sites the reference hard-codes (`.to('cuda')`, mobody.py:495-497,
+    mobody_dynamics.py:105-107,610-613,1118-1121).  No reference file is modified."""
+
+    def __enter__(self):
+        self._to = torch.Tensor.to
+
+        def to(t, *a, **k):
+            a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+            if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+                k["device"] = "cpu"
+            return self._to(t, *a, **k)
+
+        torch.Tensor.to = to
+        return self
+
+    def __exit__(self, *a):
+        torch.Tensor.to = self._to
+
+
+REFRESH_MAP = {50000: 96, 2000: 40, 100: 12}     # hard-coded refresh sizes (mobody.py:442-443,484-485) -> fixture sizes
+
+
+def shrink_samples(rb, name, log):
+    """The reference hard-codes sample(50000)/sample(2000)/sample(100) in the refresh; the harness maps them to small
+    counts (the mirror's test patches its module constants to the same numbers) and logs the order of the draws."""
+    orig = rb.sample
+
+    def sample(n):
+        n = REFRESH_MAP.get(n, n)
+        log.append((name, n))
+        return orig(n)
+
+    rb.sample = sample
+
+
+def _ref_buffer(S, A, cap, rows):
+    rb = ref_utils.ReplayBuffer(S, A, "cpu", max_size=cap)
+    s, a, s2, r, nd = rows
+    rb.add_batch(dict(obss=torch.from_numpy(s), next_obss=torch.from_numpy(s2), actions=torch.from_numpy(a),
+                      rewards=torch.from_numpy(r), terminals=torch.from_numpy(1.0 - nd)))
+    return rb
+
+
+def g11():
+    """First train() call (total_it 0 -> 1): the fake-buffer refresh of mobody.py:441-513 in the reference's order
+    (src rollout -> add -> trg rollout -> add -> (s,a) relabel with strict '<' -> [rollout_from_src]) followed by
+    the gradient step on src|tar|fake rows, through the reference's own ReplayBuffers (the fake ring wraps)."""
+    S, A, bs = 17, 6, 32
+    m, p = load_dyn(S, A, 201, 0, 0.85)
+    for tag, over in (("default", {}), ("fromsrc", dict(rollout_from_src=1, rollout_from_src_length=2))):
+        def run(env_filter, record):
+            cfg = policy_cfg(S, A, src_rollout_length=2, trg_rollout_length=3, env_filter=env_filter, **over)
+            pol, pa, pq, pv = make_policy(cfg, 401)
+            pc = {}
+            pc.update({"sa_classifier." + k: v for k, v in gi.mlp_params(701, S + A, 2).items()})
+            pc.update({"sas_classifier." + k: v for k, v in gi.mlp_params(702, 2 * S + A, 2).items()})
+            load_mlp(pol.classifier, pc)
+            dyn = MOBODYEnsembleDynamics(cfg, m, None, None, get_termination_fn("walker2d-medium-v2"), penalty_coef=0.1)
+            pol.dynamics = dyn
+            log = []
+            src = _ref_buffer(S, A, 300, gi.batch(801, 300, S, A)); shrink_samples(src, "src", log)
+            tar = _ref_buffer(S, A, 120, gi.batch(802, 120, S, A)); shrink_samples(tar, "tar", log)
+            pol.fake_replay_buffer = ref_utils.ReplayBuffer(S, A, "cpu", max_size=260)
+            shrink_samples(pol.fake_replay_buffer, "fake", log)
+            pens = []
+            o_step = dyn.step
+
+            def step(*a, **k):
+                r = o_step(*a, **k); pens.append(r[3]["penalty"].numpy().copy()); return r
+
+            dyn.step = step
+            rec = dict(q_loss=[], pi_loss=[], bc_loss=[])
+            for nm, key in (("update_q_functions", "q_loss"), ("update_policy", "pi_loss"), ("bc_loss", "bc_loss")):
+                def mk(orig, key):
+                    def f(*a, **k):
+                        o = orig(*a, **k); rec[key].append(float(o.detach())); return o
+                    return f
+                setattr(pol, nm, mk(getattr(pol, nm), key))
+            taps = dict(perm=[], noise=[])
+            o_perm, o_randn = torch.randperm, torch.randn_like
+
+            def randperm(n, **k):
+                q = o_perm(n, **k); taps["perm"].append(q.numpy().copy()); return q
+
+            def randn_like(x, **k):
+                e = o_randn(x); taps["noise"].append(e.numpy().copy()); return e
+
+            torch.randperm, torch.randn_like = randperm, randn_like
+            dummy = types.SimpleNamespace(log=lambda *a, **k: None)
+            try:
+                np.random.seed(31); torch.manual_seed(31)
+                with RngTap(900) as tap, CudaAlias():
+                    pol.train(src, tar, bs, None, dummy)
+            finally:
+                torch.randperm, torch.randn_like = o_perm, o_randn
+            return dict(pol=pol, tap=tap, pens=pens, log=log, rec=rec, taps=taps, cfg=cfg, pa=pa, pq=pq, pc=pc)
+
+        dry = run(1e9, False)
+        allp = np.unique(np.concatenate([x.ravel() for x in dry["pens"]]))
+        mid = len(allp) // 2
+        env_filter = float(0.5 * (float(allp[mid - 1]) + float(allp[mid])))      # between two penalties: well conditioned
+        r = run(env_filter, True)
+        pol, tap, fb = r["pol"], r["tap"], r["pol"].fake_replay_buffer
+        out = dict(S=S, A=A, bs=bs, dyn_seed=201, alive_val=0.85, seed=401, wsum_dyn=gi.checksum(p),
+                   wsum_actor=gi.checksum(r["pa"]), wsum_q=gi.checksum(r["pq"]), wsum_cls=gi.checksum(r["pc"]),
+                   env_filter=env_filter, n_steps=len(tap.eps), fake_cap=260, np_seed=31,
+                   refresh_src=REFRESH_MAP[50000], refresh_tar=REFRESH_MAP[2000], refresh_from_src_tar=REFRESH_MAP[100],
+                   draw_log=np.array([f"{n}:{k}" for n, k in r["log"]]), fake_ptr=fb.ptr, fake_size=fb.size,
+                   fake_state=fb.state.numpy(), fake_action=fb.action.numpy(), fake_next_state=fb.next_state.numpy(),
+                   fake_reward=fb.reward.numpy(), fake_not_done=fb.not_done.numpy(),
+                   q_loss=np.array(r["rec"]["q_loss"]), pi_loss=np.array(r["rec"]["pi_loss"]),
+                   bc_loss=np.array(r["rec"]["bc_loss"]), total_it=pol.total_it,
+                   cfg_keys=np.array(sorted(over)), cfg_vals=np.array([str(over[k]) for k in sorted(over)]))
+        for t, (e, i) in enumerate(zip(tap.eps, tap.idx)):
+            out[f"eps{t}"] = e; out[f"idx{t}"] = i; out[f"pen{t}"] = r["pens"][t]
+        if r["taps"]["perm"]:
+            out["cls_perm"] = r["taps"]["perm"][0]; out["cls_noise_sas"] = r["taps"]["noise"][0]; out["cls_noise_sa"] = r["taps"]["noise"][1]
+            for k, v in pol.classifier.state_dict().items():
+                out["cls_p::" + k] = sub(v.numpy())
+        for nm, mod in (("q", pol.q_funcs), ("actor", pol.policy), ("qt", pol.target_q_funcs)):
+            for k, v in mod.state_dict().items():
+                out[f"s1_{nm}_p::{k}"] = sub(v.numpy())
+        print("refresh", tag, "steps", len(tap.eps), "rows/step", [e.shape[1] for e in tap.eps], "draws", r["log"],
+              "fake ptr/size", fb.ptr, fb.size, "env_filter", env_filter, "losses", r["rec"])
+        save(f"g11_refresh_{tag}", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9", "g9b", "g11"]
     for w in which:
         globals()[w]()

@@ -20,7 +20,7 @@ def sub(x):
 
 def dyn_params_for(g):
     """Regenerate the dynamics weights a g234/g6 fixture was produced with and verify the checksum."""
-    seed = int(g["seed"]) if "seed" in g else int(g["dyn_seed"])
+    seed = int(g["dyn_seed"]) if "dyn_seed" in g else int(g["seed"])
     S, A = int(g["S"]), int(g["A"])
     p = gi.dyn_params(seed, S, A)
     ad = int(g["alive_dim"]) if "alive_dim" in g else 0
@@ -40,15 +40,9 @@ def policy_params(seed, S, A):
 
 
 def policy_cfg(S, A, **over):
-    cfg = dict(gamma=0.99, tau=0.005, update_interval=2, state_dim=S, action_dim=A, penalty_type="none",
-               hidden_sizes=256, max_action=1.0, critic_lr=3e-4, actor_lr=3e-4, gaussian_noise_std=1.0,
-               penalize_fake=0, src_ratio=1, trg_ratio=1, src_rollout_length=1, trg_rollout_length=1,
-               use_src_sa_to_get_target_next_state=1, env_filter=10.0, rollout_from_src=0, fake_batch_scale=0.5,
-               advantage=0, scale_Q=1, weight=2.5, bc_coef=1.0, q_weighted=1, filter_bad_rollout=1,
-               penalty_coef=0.1, mopo=0, latent_reward=0, encoder_loss_coef=1, domain_loss_coef=0.0,
-               cycle_loss_coef=0.3)
-    cfg.update(over)
-    return cfg
+    """MOBODY config of the reference's yaml + CLI defaults; lives in the package (mobody_amd.engine.default_config)."""
+    from mobody_amd.engine import default_config
+    return default_config(S, A, **over)
 
 
 G7_VARIANTS = dict(default={}, noqw=dict(q_weighted=0), adv=dict(advantage=1), noscale=dict(scale_Q=0),

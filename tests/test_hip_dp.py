@@ -27,17 +27,20 @@ def _worker(rank, world, port, tmp):
     S, A, bs, task = 17, 6, 256, "walker2d-medium-v2"
 
     def make(graph):
-        cfg = gu.policy_cfg(S, A, rng="device", seed=rank, penalty_type="none", batch_size=bs, graph=graph,
+        # the SAME config seed on every rank and DIFFERENT initial weights: the mirror itself has to fold the rank into
+        # its index streams and broadcast rank 0's replica before the first step (sync_replicas)
+        cfg = gu.policy_cfg(S, A, rng="device", seed=0, penalty_type="none", batch_size=bs, graph=graph,
                             fake_batch_scale=0.5)
-        torch.manual_seed(0); np.random.seed(0)                   # same initial weights on every rank
+        torch.manual_seed(rank); np.random.seed(rank)
         pol = call_algo("mobody", cfg, 3, dev)
-        pa, pq, _ = gu.policy_params(5, S, A)
-        pol.policy.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
-        pol.q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
-        pol.target_q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
-        src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=4000, rng="device", seed=100 + rank), 4000, task, rank)
-        tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=500, rng="device", seed=200 + rank), 500, task, 50 + rank)
-        fake = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=3000, rng="device", seed=300 + rank), 3000, task, 90 + rank)
+        if rank == 0:
+            pa, pq, _ = gu.policy_params(5, S, A)
+            pol.policy.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
+            pol.q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+            pol.target_q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+        src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=4000, rng="device", seed=100), 4000, task, 0)
+        tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=500, rng="device", seed=200), 500, task, 50)
+        fake = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=3000, rng="device", seed=300), 3000, task, 90)
         pol.fake_replay_buffer = fake
         pol.total_it = 1                                           # past the refresh step (no dynamics model here)
         return pol, src, tar
@@ -54,9 +57,9 @@ def _worker(rank, world, port, tmp):
                 pol.total_it += 1
                 c = torch.tensor([call], dtype=torch.int64, device=dev)
                 fb = pol.fake_replay_buffer
-                idx = [ops.sample_indices(rank + 101, 3, c, 0, bs, src.ptr_size[1:2]),
-                       ops.sample_indices(rank + 102, 3, c, 0, bs, tar.ptr_size[1:2]),
-                       ops.sample_indices(rank + 103, 3, c, 0, bs // 2, fb.ptr_size[1:2])]
+                idx = [ops.sample_indices(pol._seed_for(101), 3, c, 0, bs, src.ptr_size[1:2]),
+                       ops.sample_indices(pol._seed_for(102), 3, c, 0, bs, tar.ptr_size[1:2]),
+                       ops.sample_indices(pol._seed_for(103), 3, c, 0, bs // 2, fb.ptr_size[1:2])]
                 ops.gather_batch([src._fields(), tar._fields(), fb._fields()], idx, S, A, out=pol._batch)
                 pol._update(pol._batch, int(2.5 * bs), 2 * bs)
         torch.cuda.synchronize()
@@ -90,6 +93,8 @@ def test_two_rank_train_eager_equals_segment_graphs(tmp_path):
             np.testing.assert_allclose(r0[1][k].numpy(), r0[0][k].numpy(), rtol=1e-6, atol=1e-8, err_msg=k)
     k = "network1.network.0.weight"
     assert not np.allclose(r0[0][k].numpy(), pq[k])                         # and the step did something
+    # same config seed, yet the ranks drew different rows: their local loss shares differ
+    assert not torch.equal(r0[0]["losses"], r1[0]["losses"])
 
 
 def _nccl_worker(rank, world, port, tmp):

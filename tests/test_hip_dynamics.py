@@ -81,25 +81,28 @@ def test_dyn_step_empty_batch(dev):
 
 
 def test_termination_predicates_vs_golden(dev):
-    """terminal flags through the kernel for crafted next_obs (boundary values, NaN/Inf)."""
+    """The predicate FUSED in k_dyn_sample sees the G5 rows themselves (boundary values 0.8, 2.0, +-1, +-100, NaN, Inf).
+    Model: all weights zero and transition3.bias = c_e * 1 with c = (-1,-1,-1,0,1,1,1), so every mean is its member's
+    constant, the ensemble mean is exactly 0 and the unbiased std exactly 1 (6/6); with elite member 3 (mean 0) and
+    noise[3] = the fixture row, next_obs = 0 + row * 1 = the row, bit for bit -- then terminal must equal the
+    reference's flag for that row."""
     from mobody_amd import ops, packing, _lib
     g = gu.load("g5_termination")
+    c = np.array([-1, -1, -1, 0, 1, 1, 1], np.float32)
     for t in sorted({k.split("::")[0] for k in g if "::" in k}):
         n = g[t + "::next_obs"]
         B, S = n.shape
         A = 6
-        # a dynamics model whose output is exactly `n`: zero weights, transition3 bias per row is impossible,
-        # so instead drive the predicate through zero noise + identical members via mean_out override:
-        p = gu.gi.dyn_params(3, S, A)
-        for k in p:
-            p[k] = np.zeros_like(p[k])
+        p = {k: np.zeros_like(v) for k, v in gu.gi.dyn_params(3, S, A).items()}
+        p["transition3.bias"] = np.broadcast_to(c[:, None, None], (7, 1, S)).astype(np.float32).copy()
         blob = packing.pack_dynamics(p, S, A, dev)
-        # all-zero model -> mean == 0, std == 0; next_obs = 0 + eps*0 = 0 -> predicate on zeros only checks plumbing
+        noise = np.zeros((7, B, S), np.float32)
+        noise[3] = n
         r = ops.dyn_step(blob, S, A, _lib.TERM_IDS[O.resolve_task(t)], torch.zeros(B, S, device=dev),
-                         torch.zeros(B, A, device=dev), noise=np.zeros((7, B, S), np.float32),
-                         elite_idx=np.zeros(B, np.int64))
-        want0 = O.termination(t, np.zeros((B, S), np.float32), None, np.zeros((B, S), np.float32))
-        assert (r["terminal"].cpu().numpy().astype(bool) == want0).all(), t
+                         torch.zeros(B, A, device=dev), noise=noise, elite_idx=np.full(B, 3, np.int64))
+        got = r["next_obs"].cpu().numpy()
+        assert np.array_equal(got, n, equal_nan=True), t                    # the kernel's rows ARE the fixture rows
+        assert (r["terminal"].cpu().numpy().astype(bool) == g[t + "::done"]).all(), t
 
 
 def test_device_rng_matches_cpu_twin(dev):
@@ -161,3 +164,27 @@ def test_mlp3_forward_actor_and_twin_q(S, A, dev):
     for m, pre in enumerate(("network1.", "network2.")):
         for k, v in back[m].items():
             close(v, pq[pre + k], rtol=0, atol=0)
+
+
+def test_nan_member_poisons_penalty_and_row_is_dropped(dev):
+    """One non-finite ensemble member: torch.amax propagates the NaN norm (mobody_dynamics.py:246-249), so the
+    reference's `penalty <= env_filter` (mobody.py:649) and `penalty < env_filter` (:466) are False and the row never
+    reaches the fake buffer.  The kernel's max must not swallow the NaN (fmaxf would)."""
+    from mobody_amd import ops, packing
+    S, A, B = 17, 6, 70
+    p = gu.gi.dyn_params(7, S, A)
+    p["transition3.bias"][:, 0, 0] += np.float32(0.85)
+    p["transition3.bias"][2, 0, 5] = np.nan
+    blob = packing.pack_dynamics(p, S, A, dev)
+    rng = np.random.default_rng(3)
+    obs = gu.gi.walker_like_obs(rng, B, S); act = rng.uniform(-1, 1, (B, A)).astype(np.float32)
+    eps = rng.standard_normal((7, B, S)).astype(np.float32); idx = rng.integers(0, 5, B)
+    with torch.no_grad():
+        want = O.dyn_step(O.to_torch(p), obs, act, eps, idx, "walker2d-medium-v2", penalty_coef=0.1)
+    assert np.isnan(want["penalty"].numpy()).all()
+    got = ops.dyn_step(blob, S, A, 4, torch.from_numpy(obs).to(dev), torch.from_numpy(act).to(dev), noise=eps,
+                       elite_idx=idx, penalty_coef=0.1)
+    assert torch.isnan(got["penalty"]).all()
+    keep = torch.empty(B, dtype=torch.uint8, device=dev); alive = torch.empty(B, dtype=torch.uint8, device=dev)
+    ops.rollout_mask(None, got["terminal"], got["penalty"], 1e9, True, keep, alive)
+    assert int(keep.sum()) == 0

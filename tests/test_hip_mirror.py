@@ -402,3 +402,142 @@ def test_graph_mode_across_refresh_boundaries(dev, monkeypatch):
     assert pol._ctr.tolist()[1:] == [130, 130]
     assert all(np.isfinite(v) for v in pol.losses())
     assert torch.isfinite(pol.policy.blob).all() and torch.isfinite(pol.q_funcs.blob).all()
+
+
+def _mirror_buffer(rows, S, A, cap, dev):
+    from mobody_amd.algo import utils
+    rb = utils.ReplayBuffer(S, A, dev, max_size=cap)
+    s, a, s2, r, nd = rows
+    rb.add_batch(dict(obss=s, actions=a, next_obss=s2, rewards=r, terminals=1.0 - nd))
+    return rb
+
+
+def _refresh_policy(g, cfg, dev, monkeypatch):
+    """MOBODY mirror set up like make_golden.g11: reference weights, small real ring buffers, patched refresh sizes."""
+    from mobody_amd.algo.offline_offline import mobody as M
+    S, A = int(g["S"]), int(g["A"])
+    monkeypatch.setattr(M, "REFRESH_SRC", int(g["refresh_src"]))
+    monkeypatch.setattr(M, "REFRESH_TAR", int(g["refresh_tar"]))
+    monkeypatch.setattr(M, "REFRESH_FROM_SRC_TAR", int(g["refresh_from_src_tar"]))
+    pol = M.MOBODY(cfg, dev)
+    pa, pq, _ = gu.policy_params(int(g["seed"]), S, A)
+    pol.policy.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
+    pol.q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+    pol.target_q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+    pc = {}
+    pc.update({"sa_classifier." + k: v for k, v in gu.gi.mlp_params(701, S + A, 2).items()})
+    pc.update({"sas_classifier." + k: v for k, v in gu.gi.mlp_params(702, 2 * S + A, 2).items()})
+    pol.classifier.load_state_dict({k: torch.from_numpy(v) for k, v in pc.items()})
+    pol.dynamics = make_dynamics(gu.dyn_params_for(g), S, A, "walker2d-medium-v2", dev, cfg)
+    src = _mirror_buffer(gu.gi.batch(801, 300, S, A), S, A, 300, dev)
+    tar = _mirror_buffer(gu.gi.batch(802, 120, S, A), S, A, 120, dev)
+    from mobody_amd.algo import utils
+    pol.fake_replay_buffer = utils.ReplayBuffer(S, A, dev, max_size=int(g["fake_cap"]))
+    return pol, src, tar
+
+
+@pytest.mark.parametrize("tag", ["default", "fromsrc"])
+def test_mirror_refresh_step_vs_reference_golden(tag, dev, monkeypatch):
+    """The FIRST train() call (total_it 0 -> 1) against the reference (fixture g11): refresh order
+    src rollout -> add -> trg rollout -> add -> (s,a) relabel with strict '<' -> [rollout_from_src with a classifier
+    step and the DARA reward term], the NumPy index/elite stream consumed in the reference's order, the fake ring's
+    contents / ptr / size (it wraps in 'fromsrc'), then the gradient step on src|tar|fake rows."""
+    from test_hip_train import params_close
+    g = gu.load(f"g11_refresh_{tag}")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    over = {k: (int(v) if v.lstrip("-").isdigit() else v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    cfg = gu.policy_cfg(S, A, src_rollout_length=2, trg_rollout_length=3, env_filter=float(g["env_filter"]), **over)
+    pol, src, tar = _refresh_policy(g, cfg, dev, monkeypatch)
+    n = int(g["n_steps"])
+    feed(pol.dynamics, [g[f"eps{t}"] for t in range(n)])
+    if tag == "fromsrc":                       # the reference permutes the rows before adding iid noise: un-permute it
+        inv = np.argsort(g["cls_perm"])
+        pol.classifier_noise_fn = lambda rows: (torch.from_numpy(g["cls_noise_sas"][inv]).to(dev),
+                                                torch.from_numpy(g["cls_noise_sa"][inv]).to(dev))
+    np.random.seed(int(g["np_seed"]))
+    pol.train(src, tar, bs, None, None)
+    fb = pol.fake_replay_buffer
+    assert pol.total_it == 1 and (fb.ptr, fb.size) == (int(g["fake_ptr"]), int(g["fake_size"]))
+    assert pol.dynamics._calls == n
+    for f in ("state", "action", "next_state", "reward", "not_done"):
+        close(getattr(fb, f), g["fake_" + f], rtol=1e-5, atol=1e-5)
+    q_loss, pi_loss, bc_loss = pol.losses()
+    close(q_loss, g["q_loss"][0], rtol=1e-5, atol=0)
+    close(pi_loss, g["pi_loss"][0], rtol=5e-5, atol=2e-5)
+    close(bc_loss, g["bc_loss"][0], rtol=5e-5, atol=2e-5)
+    for nm, net in (("q", pol.q_funcs), ("actor", pol.policy), ("qt", pol.target_q_funcs)):
+        for k, v in net.state_dict().items():
+            params_close(gu.sub(v.cpu().numpy()), g[f"s1_{nm}_p::{k}"], cfg["critic_lr"])
+    if tag == "fromsrc":
+        for k, v in pol.classifier.state_dict().items():
+            params_close(gu.sub(v.cpu().numpy()), g["cls_p::" + k], cfg["actor_lr"], max_frac=0.5)
+
+
+def test_mirror_relabel_filter_is_strict(dev, monkeypatch):
+    """mobody.py:466 keeps rows with penalty < env_filter (strict), the rollout filter (:649) penalty <= env_filter.
+    env_filter is set to the HIP path's own penalty of one relabelled row: that row must be dropped by the relabel
+    step, and a rollout row with exactly that penalty kept."""
+    g = gu.load("g11_refresh_default")
+    S, A = int(g["S"]), int(g["A"])
+    cfg = gu.policy_cfg(S, A, src_rollout_length=0, trg_rollout_length=0, env_filter=1e9)
+    pol, src, tar = _refresh_policy(g, cfg, dev, monkeypatch)
+    np.random.seed(5)
+    idx = src.draw_indices(int(g["refresh_src"]))
+    rows = src.sample_all()
+    pen = pol.dynamics.step_device(rows[0][idx.long()], rows[1][idx.long()])["penalty"].flatten()
+    thr = float(torch.sort(pen).values[len(pen) // 2])
+    n_lt, n_le = int((pen < thr).sum()), int((pen <= thr).sum())
+    assert n_le > n_lt
+    pol.config["env_filter"] = thr
+    np.random.seed(5)
+    pol._refresh(src, tar, 32)                                   # same draws: src(96), tar(40), relabel
+    assert pol.fake_replay_buffer.size == n_lt                  # strict: the boundary row(s) are dropped
+    # rollout filter on the same penalties is inclusive
+    pol.config.update(src_rollout_length=1, use_src_sa_to_get_target_next_state=0)
+    pol.fake_replay_buffer.size = 0; pol.fake_replay_buffer.ptr = 0
+    act = pol.policy(rows[0][idx.long()])
+    pen2 = pol.dynamics.step_device(rows[0][idx.long()], act)["penalty"].flatten()
+    thr2 = float(torch.sort(pen2).values[len(pen2) // 2])
+    pol.config["env_filter"] = thr2
+    np.random.seed(5)
+    pol._refresh(src, tar, 32)
+    assert pol.fake_replay_buffer.size == int((pen2 <= thr2).sum())
+
+
+def test_dara_penalize_fake_vs_reference_golden(dev):
+    """penalize_fake=1 (fixture g9_dara_penfake): the mirror's own update_classifier (no rows/labels supplied) must draw
+    src(bs), tar(bs), fake(bs), tar(2bs) in the reference's order (mobody.py:147-154) and train on src (label 0) |
+    fake (label 1) rows -- the reference's labels cover 2*bs rows only, so its target rows never reach the classifier."""
+    from mobody_amd import packing
+    from mobody_amd.algo.offline_offline.mobody import MOBODY
+    from test_hip_train import params_close
+    g = gu.load("g9_dara_penfake")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    cfg = gu.policy_cfg(S, A, penalty_type="dara", penalize_fake=1)
+    pol = MOBODY(cfg, dev)
+    pc = {}
+    pc.update({"sa_classifier." + k: v for k, v in gu.gi.mlp_params(int(g["seed_sa"]), S + A, 2).items()})
+    pc.update({"sas_classifier." + k: v for k, v in gu.gi.mlp_params(int(g["seed_sas"]), 2 * S + A, 2).items()})
+    pol.classifier.load_state_dict({k: torch.from_numpy(v) for k, v in pc.items()})
+    log = []
+
+    def logged(name, seed):
+        rb = FixedRows(gu.gi.batch(seed, 64, S, A), S, A, dev).rb
+        rb.draw_indices = lambda n: (log.append(f"{name}:{n}"), torch.arange(n, dtype=torch.int32, device=dev))[1]
+        return rb
+
+    src, tar = logged("src", 704), logged("tar", 705)
+    pol.fake_replay_buffer = logged("fake", 706)
+    inv = np.argsort(g["perm"])                    # the reference permutes rows, then adds iid noise: un-permute the noise
+    td = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    pol.classifier_noise_fn = lambda rows: (td(g["noise_sas"][inv]), td(g["noise_sa"][inv]))
+    loss_sa, loss_sas = pol.update_classifier(src, tar, bs)
+    assert log == [str(x) for x in g["draw_log"]], log
+    close(float(loss_sa), float(g["loss_sa"]), rtol=1e-5, atol=0)
+    close(float(loss_sas), float(g["loss_sas"]), rtol=1e-5, atol=0)
+    scale = max(float(np.abs(g[k]).max()) for k in g if k.startswith("cls_g::"))
+    for net, opt in ((pol.classifier.sa_classifier, pol.classifier.opt_sa), (pol.classifier.sas_classifier, pol.classifier.opt_sas)):
+        for k, v in packing.unpack_mlp(opt.grad, net.in_dim, 2, 1)[0].items():
+            close(gu.sub(v.cpu().numpy()), g["cls_g::" + net.prefixes[0] + k], rtol=1e-5, atol=1e-5 * scale)
+    for k, v in pol.classifier.state_dict().items():
+        params_close(gu.sub(v.cpu().numpy()), g["cls_p::" + k], cfg["actor_lr"], max_frac=0.5)

@@ -44,49 +44,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-class Engine:
-    """Minimal driver of the C ABI for one (S, A): packed params, Adam moments, workspace."""
-
-    def __init__(self, S, A, pa, pq, dev):
-        from mobody_amd import ops, packing, _lib
-        self.ops, self.packing, self.S, self.A, self.dev = ops, packing, S, A, dev
-        self.actor = packing.pack_mlp([{k[len("network."):]: v for k, v in pa.items()}], S, A, dev)
-        self.q = packing.pack_mlp(pq, S + A, 1, dev, prefixes=["network1.", "network2."])
-        self.qt = self.q.clone()
-        self.actor_T = ops.mlp_transpose(self.actor, S, A, 1)
-        self.q_T = ops.mlp_transpose(self.q, S + A, 1, 2)
-        z = torch.zeros_like
-        self.ma, self.va, self.mq, self.vq = z(self.actor), z(self.actor), z(self.q), z(self.q)
-        self.ga, self.gq = z(self.actor), z(self.q)
-        self.t = 0
-        self.loss = torch.zeros(4, device=dev)
-        self.stats = torch.zeros(2, device=dev)
-
-    def step(self, batch, n_true, cfg, apply=True, dims=None):
-        ops = self.ops
-        S, A = self.S, self.A
-        b = [torch.as_tensor(x, dtype=torch.float32).to(self.dev).contiguous() for x in batch]
-        N = b[0].shape[0]
-        dims = dims or ops.train_dims(S, A, N, n_true)
-        hyp = ops.hyper(cfg)
-        ws = ops.train_workspace(dims, self.dev)
-        ops.critic_step(dims, hyp, self.actor, self.q, self.q_T, self.qt, b, self.gq, self.loss[0:1], ws)
-        if apply:
-            self.t += 1
-            ops.adam_polyak(S + A, 1, 2, self.q, self.q_T, self.gq, self.mq, self.vq, self.qt, self.t, cfg["critic_lr"], cfg["tau"])
-        ops.actor_forward(dims, hyp, self.actor, self.q, b[0], b[1], self.stats, ws)
-        ops.actor_backward(dims, hyp, self.actor, self.actor_T, self.q, self.q_T, b[0], b[1], self.stats, self.ga,
-                           self.loss[1:3], ws)
-        if apply:
-            ops.adam_polyak(S, A, 1, self.actor, self.actor_T, self.ga, self.ma, self.va, None, self.t, cfg["actor_lr"])
-        torch.cuda.synchronize()
-        return dict(q_loss=float(self.loss[0]), pi_loss=float(self.loss[1]), bc_loss=float(self.loss[2]))
-
-    def unpack(self, blob, which):
-        if which == "actor":
-            return {"network." + k: v for k, v in self.packing.unpack_mlp(blob, self.S, self.A, 1)[0].items()}
-        ms = self.packing.unpack_mlp(blob, self.S + self.A, 1, 2)
-        return {f"network{j + 1}." + k: v for j in range(2) for k, v in ms[j].items()}
+from mobody_amd.engine import Engine  # noqa: E402  (the C-ABI driver ships with the package)
 
 
 @pytest.mark.parametrize("tag", ["default", "noqw", "noscale", "nofake", "bc05"])

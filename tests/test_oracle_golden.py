@@ -183,3 +183,90 @@ def test_philox_known_answer():
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
     i = O.rng_index(1, 2, 3, 100000, 5)
     assert i.min() == 0 and i.max() == 4 and abs(np.bincount(i)[0] / 1e5 - 0.2) < 0.01
+
+
+def _g11_setup(g, S, A):
+    """Buffers, weights and draws of a g11 fixture (make_golden.g11), oracle side."""
+    p = O.to_torch(gu.dyn_params_for(g))
+    pa, pq, _ = gu.policy_params(int(g["seed"]), S, A)
+    assert abs(gu.gi.checksum(pa) - float(g["wsum_actor"])) < 1e-9 * abs(float(g["wsum_actor"]))
+    pc = {}
+    pc.update({"sa_classifier." + k: v for k, v in gu.gi.mlp_params(701, S + A, 2).items()})
+    pc.update({"sas_classifier." + k: v for k, v in gu.gi.mlp_params(702, 2 * S + A, 2).items()})
+    bufs = []
+    for seed, cap in ((801, 300), (802, 120)):
+        s, a, s2, r, nd = gu.gi.batch(seed, cap, S, A)
+        rb = O.RingBuffer(S, A, cap)
+        rb.add_batch(dict(obss=s, actions=a, next_obss=s2, rewards=r, terminals=1.0 - nd))
+        bufs.append(rb)
+    # elite ids are NOT passed: the oracle draws them from the NumPy global stream where the reference does, which is
+    # what keeps the later np.random.randint index draws aligned (Appendix C of SURVEY.md)
+    draws = [(g[f"eps{t}"], None) for t in range(int(g["n_steps"]))]
+    return p, pa, pq, pc, bufs[0], bufs[1], draws
+
+
+@pytest.mark.parametrize("tag", ["default", "fromsrc"])
+def test_g11_refresh_step(tag):
+    """First train() call: refresh order, strict '<' relabel filter, ring wrap, index-draw order, then the gradient step."""
+    g = gu.load(f"g11_refresh_{tag}")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    over = {k: (int(v) if v.lstrip("-").isdigit() else v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    cfg = gu.policy_cfg(S, A, src_rollout_length=2, trg_rollout_length=3, env_filter=float(g["env_filter"]), **over)
+    p, pa, pq, pc, src, tar, draws = _g11_setup(g, S, A)
+    fake = O.RingBuffer(S, A, int(g["fake_cap"]))
+    sizes = (int(g["refresh_src"]), int(g["refresh_tar"]), int(g["refresh_from_src_tar"]))
+    cls = {k: O.T(v).clone() for k, v in pc.items()}
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in cls.items()}
+
+    def classifier_update(src_rb, tar_rb, batch_size):                      # update_classifier, mobody.py:146-181
+        sb, tb = src_rb.sample(batch_size), tar_rb.sample(batch_size)
+        perm = g["cls_perm"]
+        cat = [torch.cat([sb[i], tb[i]], 0)[perm] for i in range(3)]
+        label = np.concatenate([np.zeros(batch_size), np.ones(batch_size)])[perm]
+        with torch.enable_grad():
+            pr = {k: v.clone().requires_grad_(True) for k, v in cls.items()}
+            loss = O.classifier_loss(pr, cat[0], cat[1], cat[2], label, g["cls_noise_sas"], g["cls_noise_sa"], cfg["gaussian_noise_std"])
+            grads = torch.autograd.grad(loss, list(pr.values()))
+        for (k, _), gr in zip(pr.items(), grads):
+            O.adam_update(cls[k], gr, mom[k][0], mom[k][1], 1, cfg["actor_lr"])
+
+    np.random.seed(int(g["np_seed"]))
+    ns, nt = int(cfg["src_ratio"] * bs), int(cfg["trg_ratio"] * bs)
+    sb, tb = src.sample(ns), tar.sample(nt)                                  # mobody.py:399-400 come first
+    with torch.no_grad():
+        O.refresh(O.to_torch(pa), p, src, tar, fake, cfg, "walker2d-medium-v2", draws, bs, sizes=sizes, penalty_coef=0.1,
+                  classifier_update=classifier_update, cls_p=cls)
+    assert (fake.ptr, fake.size) == (int(g["fake_ptr"]), int(g["fake_size"]))
+    for f in O.RingBuffer.FIELDS:
+        close(getattr(fake, f), g["fake_" + f], rtol=1e-5, atol=1e-6)
+    if tag == "fromsrc":
+        for k, v in cls.items():
+            close(gu.sub(v.numpy()), g["cls_p::" + k], rtol=1e-5, atol=2e-6)
+    fb = fake.sample(int(cfg["fake_batch_scale"] * bs))                       # :523
+    batch = tuple(torch.cat([sb[i], tb[i], fb[i]], 0) for i in range(5))
+    st = O.TrainState(pa, pq, None)
+    out = O.train_step(st, batch, ns + nt, cfg)
+    close(float(out["q_loss"]), g["q_loss"][0], rtol=1e-5, atol=0)
+    close(float(out["pi_loss"]), g["pi_loss"][0], rtol=2e-5, atol=0)
+    for k in st.q:
+        close(gu.sub(st.q[k].numpy()), g["s1_q_p::" + k], rtol=1e-5, atol=1e-6)
+
+
+def test_g9b_dara_penalize_fake():
+    """penalize_fake=1: rows that reach the classifier are src (label 0) | fake (label 1), mobody.py:146-165."""
+    g = gu.load("g9_dara_penfake")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    assert [str(x) for x in g["draw_log"]] == [f"src:{bs}", f"tar:{bs}", f"fake:{bs}", f"tar:{2 * bs}"]
+    pc = {}
+    pc.update({"sa_classifier." + k: v for k, v in gu.gi.mlp_params(int(g["seed_sa"]), S + A, 2).items()})
+    pc.update({"sas_classifier." + k: v for k, v in gu.gi.mlp_params(int(g["seed_sas"]), 2 * S + A, 2).items()})
+    src = gu.gi.batch(704, 64, S, A); fake = gu.gi.batch(706, 64, S, A)
+    perm = g["perm"]
+    assert len(perm) == 2 * bs
+    cat = [np.concatenate([src[i][:bs], fake[i][:bs]], 0)[perm] for i in range(3)]
+    label = np.concatenate([np.zeros(bs), np.ones(bs)])[perm]
+    pr = {k: v.clone().requires_grad_(True) for k, v in O.to_torch(pc).items()}
+    loss = O.classifier_loss(pr, cat[0], cat[1], cat[2], label, g["noise_sas"], g["noise_sa"], 1.0)
+    close(float(loss.detach()), float(g["loss_sa"]) + float(g["loss_sas"]), rtol=1e-5)
+    for (k, _), gr in zip(pr.items(), torch.autograd.grad(loss, list(pr.values()))):
+        close(gu.sub(gr.numpy()), g["cls_g::" + k], rtol=2e-4, atol=2e-7)
