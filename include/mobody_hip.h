@@ -14,6 +14,7 @@
  *   mobody_actor_forward / mobody_actor_backward
  *                        <- update_policy + bc_loss + backward    mobody.py:246-276,314-345,555-572
  *   mobody_adam_polyak   <- Adam.step + update_target             mobody.py:127-131,183-187,548,552,573
+ *   mobody_pretrain_*    <- MOBODYEnsembleDynamics.learn / validate  algo/dynamics/mobody_dynamics.py:300-384,594-653,1113-1140
  *   mobody_rng_*         <- torch.normal / np.random.choice / np.random.randint draws
  *                           (mobody_dynamics.py:220, mobody_module.py:355-357, utils.py:128)
  *
@@ -288,6 +289,56 @@ int mobody_dara_loss_grad(const float* z_sas, const float* z_sa, const int32_t* 
  * reward[i] += coef * delta (reward may be NULL), delta_out optional. */
 int mobody_dara_penalty(const float* z_sas, const float* z_sa, int64_t n, float coef, float* reward, float* delta_out,
                         void* stream);
+
+/* ---- dynamics pre-training (MOBODYEnsembleDynamics.learn / validate, algo/dynamics/mobody_dynamics.py:300-384,
+ *      594-653, 1113-1140; Swish/reparameterisation mobody_module.py:9-15,237-243) ----------------------------------
+ * All trained parameters of the 7-member ensemble live in ONE blob: three MobodyMlpLayout regions with 7 members
+ * (state encoder zs1-3: S -> 256 -> 256 -> 32 = mu | logvar; decoder transition1-3: 16 -> 256 -> 256 -> S; reward head
+ * reward_model1-3: 2S+A -> 256 -> 256 -> 2) and the two action encoders (za_src*, za_trg*), per member
+ * W1[16+A][32] b1[32] W2[32][16] b2[16] row major (only the mu half of za_*2 takes part in the loss).  Gradients and
+ * both Adam moments use the same layout; the T blob holds the three regions' transposes. */
+typedef struct MobodyPretrainLayout {
+  int32_t S, A, za_in, _pad;
+  MobodyMlpLayout enc, tr, rw;
+  int64_t off_enc, off_tr, off_rw, off_za_src, off_za_trg;    /* float offsets inside the parameter blob */
+  int64_t za_w1, za_b1, za_w2, za_b2, za_member_floats;       /* inside one member of an action encoder */
+  int64_t total_floats;
+  int64_t t_off_enc, t_off_tr, t_off_rw, t_total_floats;      /* T blob */
+} MobodyPretrainLayout;
+int mobody_pretrain_layout(int S, int A, MobodyPretrainLayout* out);
+int mobody_pretrain_transpose(int S, int A, const float* blob, float* blob_T, void* stream);
+int64_t mobody_pretrain_workspace(int S, int A, int64_t b);
+
+/* Bootstrap gather of one batch (learn() slices train_obss[:, k*bs:(k+1)*bs] of the per-member bootstrapped arrays,
+ * :604-612): member e takes dataset rows idx[e][start + r], r < b.  idx is a DEVICE int32 [7][n_idx] matrix.
+ * Outputs: xenc[7][2b][S] (s rows, then s' rows), act[7][b][A], rew[7][b]. */
+int mobody_pretrain_gather(const float* state, const float* action, const float* next_state, const float* reward,
+                           const int32_t* idx, int64_t n_idx, int64_t start, int64_t b, int S, int A, float* xenc,
+                           float* act, float* rew, void* stream);
+
+/* Loss and gradients of one learn() batch (zero_grad + loss.backward, :594-642).  b rows per member on this rank,
+ * b_global = rows per member over all data-parallel ranks (gradients / losses are local shares of the global means:
+ * SUM all-reduce `grad` before mobody_pretrain_adam).  noise6 [6][7][b][16] = the six reparameterisation draws in the
+ * reference's order z1(s) z2(s') z3(s) z4(s') z5(s) z6(s), noise7 [7][b][S] = the fake-next-state draw; NULL -> device
+ * Philox streams 16..22 at (seed, call).  grad: blob layout; the action encoder that is not used this step
+ * (za_trg* on source batches, za_src* on target ones) is left untouched.
+ * loss_out[5] = (loss, transition_loss, encoder_loss, recon_loss, kl_loss). */
+int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, int use_trg, float encoder_loss_coef,
+                          const float* blob, const float* blob_T, const float* xenc, const float* act, const float* rew,
+                          const float* noise6, const float* noise7, uint32_t seed, uint32_t call, float* grad,
+                          float* loss_out, float* workspace, void* stream);
+
+/* torch.optim.Adam step on the blob (and its T blob): the three MLP regions use the 1-based step count t_main, the
+ * action encoder of this step's domain t_za; the other action encoder is skipped (its .grad is None in the reference,
+ * so its Adam state does not advance). */
+int mobody_pretrain_adam(int S, int A, int use_trg, float* blob, float* blob_T, const float* grad, float* m, float* v,
+                         int64_t t_main, int64_t t_za, float lr, float grad_scale, void* stream);
+
+/* validate() (:1113-1140) on an inference blob (mobody_dyn_layout): out[0..6] = per-member mean_{b,d}(mean_e - s')^2,
+ * out[7..13] = per-member mean_b (r_mu_e(s, a, mean_e) - r)^2.  Workspace floats: mobody_dyn_validate_workspace. */
+int64_t mobody_dyn_validate_workspace(int S, int A, int64_t B);
+int mobody_dyn_validate(const float* dyn_blob, int S, int A, const float* obs, const float* act, const float* next_obs,
+                        const float* rew, int64_t B, int use_trg, float* out, float* workspace, void* stream);
 
 /* (Re)build the transposed blob from a parameter blob (after loading a checkpoint). */
 int mobody_mlp_transpose(int in_dim, int out_dim, int members, const float* blob, float* blob_T, void* stream);

@@ -33,6 +33,14 @@ class MobodyMlpLayout(C.Structure):
                 ("t_member_floats", i64), ("t_total_floats", i64)]
 
 
+class MobodyPretrainLayout(C.Structure):
+    _fields_ = [("S", i32), ("A", i32), ("za_in", i32), ("_pad", i32), ("enc", MobodyMlpLayout), ("tr", MobodyMlpLayout),
+                ("rw", MobodyMlpLayout), ("off_enc", i64), ("off_tr", i64), ("off_rw", i64), ("off_za_src", i64),
+                ("off_za_trg", i64), ("za_w1", i64), ("za_b1", i64), ("za_w2", i64), ("za_b2", i64),
+                ("za_member_floats", i64), ("total_floats", i64), ("t_off_enc", i64), ("t_off_tr", i64),
+                ("t_off_rw", i64), ("t_total_floats", i64)]
+
+
 class MobodyBufferView(C.Structure):
     _fields_ = [("state", vp), ("action", vp), ("next_state", vp), ("reward", vp), ("not_done", vp)]
 
@@ -95,6 +103,15 @@ PROTOTYPES = {
     "mobody_dara_loss_grad": (C.c_int, [vp, vp, vp, i64, i64, vp, vp, vp, vp, vp]),
     "mobody_dara_penalty": (C.c_int, [vp, vp, i64, f32, vp, vp, vp]),
     "mobody_mlp_transpose": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "mobody_pretrain_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(MobodyPretrainLayout)]),
+    "mobody_pretrain_transpose": (C.c_int, [C.c_int, C.c_int, vp, vp, vp]),
+    "mobody_pretrain_workspace": (i64, [C.c_int, C.c_int, i64]),
+    "mobody_pretrain_gather": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "mobody_pretrain_grads": (C.c_int, [C.c_int, C.c_int, i64, i64, C.c_int, f32, vp, vp, vp, vp, vp, vp, vp, u32, u32,
+                                        vp, vp, vp, vp]),
+    "mobody_pretrain_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, i64, i64, f32, f32, vp]),
+    "mobody_dyn_validate_workspace": (i64, [C.c_int, C.c_int, i64]),
+    "mobody_dyn_validate": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp]),
 }
 
 _lib = None
@@ -163,4 +180,10 @@ def dyn_layout(S, A):
 def mlp_layout(in_dim, out_dim, members):
     L = MobodyMlpLayout()
     check(load().mobody_mlp_layout(in_dim, out_dim, members, C.byref(L)), "mobody_mlp_layout")
+    return L
+
+
+def pretrain_layout(S, A):
+    L = MobodyPretrainLayout()
+    check(load().mobody_pretrain_layout(S, A, C.byref(L)), "mobody_pretrain_layout")
     return L

@@ -270,7 +270,11 @@ class MOBODY(object):
             out = (torch.empty(N, self.S, device=self.device), torch.empty(N, self.A, device=self.device),
                    torch.empty(N, self.S, device=self.device), torch.empty(N, 1, device=self.device),
                    torch.empty(N, 1, device=self.device))
-            self._gather(bufs, counts, out)
+            o = 0
+            for k in range(0, len(bufs), 2):          # the gather kernel takes up to three sources: two per launch
+                n = sum(counts[k:k + 2])
+                self._gather(bufs[k:k + 2], counts[k:k + 2], tuple(t[o:o + n] for t in out))
+                o += n
             if use_fake:                              # rows [src | fake]
                 pick = lambda t: torch.cat([t[:batch_size], t[2 * batch_size:3 * batch_size]], 0).contiguous()
             else:                                     # rows [src | tar]

@@ -75,6 +75,32 @@ __device__ __forceinline__ void wide_layer(float* Xs, const float* __restrict__ 
   wide_layer<ACT, MT>(Xs, W, b, Kp, ring, extra, [] {});
 }
 
+// Training forward of a Swish layer: X <- y = z*sigmoid(z), z = X*W + b, and `extra(guard, row, col, y, d)` also sees
+// d = dy/dz = sig*(1 + z*(1 - sig)) (saved for the backward pass: Swish is not invertible, so the sign words of the ReLU
+// nets do not carry over; mobody_module.py:9-15).
+template <int MT, class Extra, class Between>
+__device__ __forceinline__ void wide_layer_swish_d(float* Xs, const float* __restrict__ W, const float* __restrict__ b,
+                                                   int Kp, WideRing& ring, Extra&& extra, Between&& between, bool full) {
+  const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
+  f32x16 acc[MT][2];
+  wide_zero<MT>(acc);
+  wide_gemm<MT>(Xs, W, Kp, acc, ring);
+  between();
+  lds_barrier();
+  auto body = [&](auto guarded) {
+    wide_foreach<MT>(acc, [&](int row, int col, float v) {
+      const float z = v + ((col & 32) ? bias1 : bias0);
+      const float sig = 1.f / (1.f + __expf(-z));
+      const float y = z * sig;
+      Xs[row * LDX + col] = y;
+      extra(guarded, row, col, y, sig * (1.f + z * (1.f - sig)));
+    });
+  };
+  if (full) body(std::false_type{});
+  else body(std::true_type{});
+  lds_barrier();
+}
+
 struct NoExtra {
   template <class Guard>
   __device__ __forceinline__ void operator()(Guard, int, int, float) const {}
@@ -83,6 +109,9 @@ struct NoExtra {
 struct Mlp3FwdArgs {
   const float* src[3];      // concatenated inputs, src[k] is [rows][n[k]] with leading dim ld[k]; unused: n = 0
   int ld[3], n[3];
+  long long src_ms[3];      // member stride of src[k] in floats: 0 = one input shared by all members (the hot path),
+                            // rows*ld = per-member rows (dynamics pre-training / validation: [E][rows][n])
+  long long x_ms;           // member stride of save_x: 0 = written once by member 0, else every member saves its own
   const float *w1, *b1, *w2, *b2, *w3, *b3;   // member 0
   long long sw1, sb1, sw2, sb2, sw3, sb3;     // member strides (floats)
   int Kp1, Np3, nout;
@@ -95,6 +124,8 @@ struct Mlp3FwdArgs {
   float* save_h2;
   uint32_t* mask1;          // [members][ceil(rows/32)][256] sign bits of h1 / h2 (optional, see wide_layer)
   uint32_t* mask2;
+  float* save_d1;           // [members][rows][256] Swish derivative at the pre-activations of layers 1 / 2 (training
+  float* save_d2;           // forward of the ensemble nets only: k_mlp3_fwd_train)
   int out_mode;             // 0 raw, 1 max_action*tanh
   float max_action;
 };

@@ -28,12 +28,15 @@ namespace mobody {
 // round trips per layer, measured 60 % SQ_WAIT_ANY) -- so all 64 are in flight together and cost one round trip.
 // (Holding them across the GEMM instead was tried: 256 VGPRs + 62 spills, slower.)
 // Lanes < 32 end up with the 64-row sums of columns 64w + 32nt + (lane&31), nt = 0,1.
-template <int MT, bool BITS>
+// MASK: 0 = ReLU mask from the saved activations (h > 0), 1 = ReLU mask from the forward's sign words,
+//       2 = Swish: multiply by the saved derivative d = dy/dz (h points at save_d of the forward, mobody_module.py:9-15).
+template <int MT, int MASK>
 __device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], float* Xs, const float* __restrict__ h,
                                                        const uint32_t* __restrict__ bits, float* gdst, int rows_here,
                                                        float (&cs)[2]) {
   const int lane = lane_id(), w = wave_id();
   const int i = lane & 31, hh = lane >> 5;
+  constexpr bool BITS = MASK == 1;
   float hv[BITS ? 1 : MT][2][BITS ? 1 : 16];
   uint32_t mw[MT][2];
   if constexpr (BITS) {                            // two words per 32-row tile and lane instead of 32 activations
@@ -65,11 +68,16 @@ __device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], flo
           const int rb = (r & 3) + 8 * (r >> 2) + 4 * hh;
           const int row = 32 * mt + rb;
           const int col = 64 * w + 32 * nt + i;
-          bool on;
-          if constexpr (BITS) on = (mw[mt][nt] >> rb) & 1u;
-          else on = hv[mt][nt][r] > 0.f;
           const bool valid = !decltype(guarded)::value || row < rows_here;
-          const float dz = (on && valid) ? acc[mt][nt][r] : 0.f;
+          float dz;
+          if constexpr (MASK == 2) {
+            dz = valid ? acc[mt][nt][r] * hv[mt][nt][r] : 0.f;
+          } else {
+            bool on;
+            if constexpr (BITS) on = (mw[mt][nt] >> rb) & 1u;
+            else on = hv[mt][nt][r] > 0.f;
+            dz = (on && valid) ? acc[mt][nt][r] : 0.f;
+          }
           Xs[row * LDX + col] = dz;
           if (gdst != nullptr && valid) gdst[row * HID + col] = dz;
           cs[nt] += dz;
@@ -158,9 +166,10 @@ __device__ __forceinline__ void bwd_seed(const Mlp3BwdArgs& a, float* Xs, float*
 
 // NT (DX only): 16-column tiles of the input-gradient layer handled by the K-split narrow layer (Np1t == 16*NT),
 // or 0 = any Np1t through the row-split path.
-// BITS: ReLU masks come from the forward's sign words (m1, m2) instead of the saved activations (h1, h2).
-template <bool DX, int MT, int NT, bool BITS>
+// MASK: see wide_mask_store_colsum (1: sign words m1, m2; 0: saved activations h1, h2; 2: Swish derivatives in h1, h2).
+template <bool DX, int MT, int NT, int MASK>
 __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
+  constexpr bool BITS = MASK == 1;
   __shared__ float red[8];
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   constexpr int TB = 32 * MT;
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdA
   TR(2);
   wide_prefetch(w2t, HID, ring);                  // next layer's first fragments overlap the mask epilogue
   lds_barrier();
-  wide_mask_store_colsum<MT, BITS>(acc, Xs, h2, m2, dz2, rows_here, cs);
+  wide_mask_store_colsum<MT, MASK>(acc, Xs, h2, m2, dz2, rows_here, cs);
   if (lane < 32) { dbp[HID + 64 * w + lane] = cs[0]; dbp[HID + 64 * w + 32 + lane] = cs[1]; }
   lds_barrier();
   TR(3);
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdA
   NarrowRegs<(NT > 0 ? NT : 1)> br;
   if constexpr (DX && NT > 0) narrow_prefetch<NT>(w1t, 16 * NT, br);
   lds_barrier();
-  wide_mask_store_colsum<MT, BITS>(acc, Xs, h1, m1, dz1, rows_here, cs);
+  wide_mask_store_colsum<MT, MASK>(acc, Xs, h1, m1, dz1, rows_here, cs);
   if (lane < 32) { dbp[64 * w + lane] = cs[0]; dbp[64 * w + 32 + lane] = cs[1]; }
   TR(5);
   if constexpr (DX) {
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdA
   TR(6);
 }
 
-template <bool DX, int MT, int NT, bool BITS>
+template <bool DX, int MT, int NT, int BITS>
 static int launch_bwd_t(const Mlp3BwdArgs& a, int members, hipStream_t st) {
   constexpr size_t lds = (size_t)32 * MT * LDX * sizeof(float);
   static bool once = false;
@@ -245,7 +254,7 @@ static int launch_bwd_t(const Mlp3BwdArgs& a, int members, hipStream_t st) {
 }
 
 // tile_rows (32 or 64) must be the value the caller sized `dbp` / the bias reduction with
-template <bool BITS>
+template <int BITS>
 static int launch_bwd_masks(const Mlp3BwdArgs& a, int members, bool with_dx, int tile_rows, hipStream_t st) {
   const int nt = a.Np1t == 16 ? 1 : a.Np1t == 32 ? 2 : 0;
   if (tile_rows == 32) {
@@ -258,10 +267,22 @@ static int launch_bwd_masks(const Mlp3BwdArgs& a, int members, bool with_dx, int
                                                                              : launch_bwd_t<true, 2, 0, BITS>(a, members, st);
 }
 
+// Swish nets (the ensemble dynamics, pre-training): 32-row tiles only, derivative multipliers in h1 / h2
+static int launch_bwd_swish(const Mlp3BwdArgs& a, int members, bool with_dx, hipStream_t st) {
+  const int nt = a.Np1t == 16 ? 1 : a.Np1t == 32 ? 2 : 0;
+  if (!with_dx) return launch_bwd_t<false, 1, 0, 2>(a, members, st);
+  return nt == 1 ? launch_bwd_t<true, 1, 1, 2>(a, members, st) : nt == 2 ? launch_bwd_t<true, 1, 2, 2>(a, members, st)
+                                                                         : launch_bwd_t<true, 1, 0, 2>(a, members, st);
+}
+
 int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, int tile_rows, hipStream_t st) {
   if (a.rows <= 0) return 0;
-  return a.m1 != nullptr && a.m2 != nullptr ? launch_bwd_masks<true>(a, members, with_dx, tile_rows, st)
-                                            : launch_bwd_masks<false>(a, members, with_dx, tile_rows, st);
+  if (a.swish) {
+    if (tile_rows != 32) return fail(MOBODY_E_ARG, "launch_mlp3_bwd: the Swish backward uses 32-row tiles");
+    return launch_bwd_swish(a, members, with_dx, st);
+  }
+  return a.m1 != nullptr && a.m2 != nullptr ? launch_bwd_masks<1>(a, members, with_dx, tile_rows, st)
+                                            : launch_bwd_masks<0>(a, members, with_dx, tile_rows, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -475,6 +496,29 @@ __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
     if (a.grad != nullptr) a.grad[dst] = s;
     if (a.adam.on) adam_element(a.adam, a.L, dst, s);
   }
+}
+
+// dW1, dW2, dW3 (one merged split-K launch) + the deterministic slab / bias-partial reduction (optionally with the
+// optimizer step fused).  x_mstride: 0 = the input rows are shared by the members, rows*Kp1 = per-member inputs.
+int mlp3_weight_grads(const MobodyMlpLayout& L, const float* x, long long x_mstride, const float* h1, const float* h2,
+                      const float* dz3, const float* dz2, const float* dz1, long long rows, int nsplit, float* slabs,
+                      const float* dbp, int ntiles, float* grad, const LossFinal& loss, const AdamTarget& adam,
+                      hipStream_t st) {
+  WgradArgs g{};
+  const long long slab_stride = (L.total_floats + 3) & ~3LL;
+  g.rows = rows; g.slabs = slabs; g.slab_stride = slab_stride; g.out_mstride = L.member_floats;
+  g.nsplit = nsplit; g.members = L.members;
+  const long long hs = rows * HID;
+  // dW2 = h1^T dz2
+  g.job[0] = WgradJob{h1, hs, HID, HID, dz2, hs, HID, HID, L.w2, HID, HID, HID, 0, 1, 0, 0};
+  // dW1 = x^T dz1
+  g.job[1] = WgradJob{x, x_mstride, L.Kp1, L.Kp1, dz1, hs, HID, HID, L.w1, HID, L.Kp1, HID, 0, 1, 0, 0};
+  // dW3^T = dz3^T h2, stored transposed into W3[256][Np3]
+  g.job[2] = WgradJob{dz3, rows * L.Np3, L.Np3, L.Np3, h2, hs, HID, HID, L.w3, L.Np3, L.Np3, HID, 1, 0, 0, 0};
+  int rc = launch_wgrad(g, st);
+  if (rc) return rc;
+  GradReduceArgs r{L, slabs, slab_stride, nsplit, dbp, ntiles, grad, loss, adam};
+  return launch_grad_reduce(r, st);
 }
 
 int launch_grad_reduce(const GradReduceArgs& a, hipStream_t st) {

@@ -64,17 +64,18 @@ __device__ __forceinline__ void mlp3_fwd_tile(const Mlp3FwdArgs& a, int m, float
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     if (a.n[k] > 0) {
-      tile_load(Xs, c0, a.src[k] + row0 * a.ld[k], a.ld[k], a.n[k], 0, rows_here, TB);
+      tile_load(Xs, c0, a.src[k] + m * a.src_ms[k] + row0 * a.ld[k], a.ld[k], a.n[k], 0, rows_here, TB);
       c0 += a.n[k];
     }
   }
   tile_zero_cols(Xs, c0, a.Kp1, TB);
   lds_barrier();
   TR(1);
-  if (a.save_x != nullptr && m == 0) {              // same thread <-> element map as tile_load (no division)
+  if (a.save_x != nullptr && (m == 0 || a.x_ms != 0)) {   // same thread <-> element map as tile_load (no division)
     const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    float* sx = a.save_x + m * a.x_ms;
     for (int col = c; col < a.Kp1; col += 32)
-      for (int r = r0; r < rows_here; r += (NTHREADS * RG) >> 5) a.save_x[(row0 + r) * a.Kp1 + col] = Xs[r * LDX + col];
+      for (int r = r0; r < rows_here; r += (NTHREADS * RG) >> 5) sx[(row0 + r) * a.Kp1 + col] = Xs[r * LDX + col];
   }
 
   float* h1 = a.save_h1 ? a.save_h1 + ((long long)m * a.rows + row0) * HID : nullptr;

@@ -50,7 +50,8 @@ struct Mlp3BwdArgs {
   BwdSeed seed;
   const float* dz3;        // [members][rows][Np3] (zero in padded columns); seed.mode 0 only
   const float* h1;         // [members][rows][256] post-ReLU hidden activations saved by the forward
-  const float* h2;
+  const float* h2;         // (swish != 0: the Swish derivatives save_d1 / save_d2 of k_mlp3_fwd_train instead)
+  int swish;
   const uint32_t* m1;      // [members][ceil(rows/32)][256] sign bits of h1 / h2 written by the forward; when both are
   const uint32_t* m2;      // given they replace h1 / h2 (which may then be null)
   const float* wt;         // transposed blob (member 0)
@@ -139,6 +140,8 @@ __device__ __forceinline__ void adam_element(const AdamTarget& a, const MobodyMl
   }
 }
 
+int launch_adam(const AdamTarget& a, const float* g, const MobodyMlpLayout& L, hipStream_t st);      // k_adam over one packed MLP
+
 // Final reduction of per-workgroup loss partials, done by one extra workgroup of k_grad_reduce (saves a launch).
 //   kind 1 (critic): out[0] = scale * sum parts[k]
 //   kind 2 (actor):  parts = pairs (sum -min q, sum w*(pi-a)^2);  bc = s1/ntg_a;
@@ -158,11 +161,15 @@ struct GradReduceArgs {
   AdamTarget adam;      // on = 0: none
 };
 int launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);
+int mlp3_weight_grads(const MobodyMlpLayout& L, const float* x, long long x_mstride, const float* h1, const float* h2,
+                      const float* dz3, const float* dz2, const float* dz1, long long rows, int nsplit, float* slabs,
+                      const float* dbp, int ntiles, float* grad, const LossFinal& loss, const AdamTarget& adam,
+                      hipStream_t st);
 
 // split-K factor (workgroups along the row dimension) used for a batch of `rows`: 24 output tiles x nsplit x members
 // workgroups should reach ~3 per CU (768), so a one-member net splits twice as fine as a twin net
 inline int wgrad_nsplit(long long rows, int members) {
-  const int cap = members == 1 ? 32 : 16;
+  const int cap = members == 1 ? 32 : members == 2 ? 16 : (32 / members > 1 ? 32 / members : 1);   // 7 members: 4
   long long s = rows / (members == 1 ? 128 : 256);
   if (s < 1) s = 1;
   if (s > cap) s = cap;

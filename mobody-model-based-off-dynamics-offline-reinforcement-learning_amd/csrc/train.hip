@@ -151,6 +151,12 @@ __global__ __launch_bounds__(256) void k_adam(AdamTarget a, const float* g, long
   adam_element(a, L, j, g[j]);
 }
 
+int launch_adam(const AdamTarget& a, const float* g, const MobodyMlpLayout& L, hipStream_t st) {
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)cdiv(L.total_floats, 256)), dim3(256), 0, st, a, g, (long long)L.total_floats, L);
+  MB_LAUNCH_OK("k_adam");
+  return 0;
+}
+
 // W1 and W2 (and W3T, W2T of the T blob) are 256 columns wide and stored K-interleaved (tile.h wide_idx);
 // W3 and W1T are narrow and row major.
 __global__ __launch_bounds__(256) void k_mlp_transpose(MobodyMlpLayout L, const float* blob, float* bt) {
@@ -197,22 +203,8 @@ static Mlp3FwdArgs fwd_args(const float* blob, const MobodyMlpLayout& L, const f
 static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h1, const float* h2, const float* dz3,
                         const float* dz2, const float* dz1, long long rows, const TrainWs& w, float* grad,
                         const LossFinal& loss, const AdamTarget& adam, hipStream_t st) {
-  WgradArgs g{};
-  const int nsplit = L.members == 1 ? w.nsplit_a : w.nsplit_q;
-  const long long slab_stride = (L.total_floats + 3) & ~3LL;
-  g.rows = rows; g.slabs = w.slabs; g.slab_stride = slab_stride; g.out_mstride = L.member_floats;
-  g.nsplit = nsplit; g.members = L.members;
-  const long long hs = rows * HID;
-  // dW2 = h1^T dz2
-  g.job[0] = WgradJob{h1, hs, HID, HID, dz2, hs, HID, HID, L.w2, HID, HID, HID, 0, 1, 0, 0};
-  // dW1 = x^T dz1   (x is shared by the members)
-  g.job[1] = WgradJob{x, 0, L.Kp1, L.Kp1, dz1, hs, HID, HID, L.w1, HID, L.Kp1, HID, 0, 1, 0, 0};
-  // dW3^T = dz3^T h2, stored transposed into W3[256][Np3]
-  g.job[2] = WgradJob{dz3, rows * L.Np3, L.Np3, L.Np3, h2, hs, HID, HID, L.w3, L.Np3, L.Np3, HID, 1, 0, 0, 0};
-  int rc = launch_wgrad(g, st);
-  if (rc) return rc;
-  GradReduceArgs r{L, w.slabs, slab_stride, nsplit, w.dbp, w.ntiles, grad, loss, adam};
-  return launch_grad_reduce(r, st);
+  return mlp3_weight_grads(L, x, 0, h1, h2, dz3, dz2, dz1, rows, L.members == 1 ? w.nsplit_a : w.nsplit_q, w.slabs, w.dbp,
+                           w.ntiles, grad, loss, adam, st);
 }
 
 static Mlp3BwdArgs bwd_args(const MobodyMlpLayout& L, const float* blob_T, const float* dz3, const float* h1,

@@ -310,3 +310,59 @@ def dara_penalty(z_sas, z_sa, coef, reward=None, want_delta=False):
     check(load().mobody_dara_penalty(ptr(z_sas), ptr(z_sa), n, float(coef), ptr(reward), ptr(delta), cur_stream()),
           "mobody_dara_penalty")
     return delta
+
+
+# ------------------------------------------------------------------------------------------------
+# dynamics pre-training
+# ------------------------------------------------------------------------------------------------
+def pretrain_transpose(blob, S, A, out=None):
+    L = _lib.pretrain_layout(S, A)
+    bt = out if out is not None else torch.zeros(L.t_total_floats, dtype=torch.float32, device=blob.device)
+    check(load().mobody_pretrain_transpose(S, A, ptr(blob), ptr(bt), cur_stream()), "mobody_pretrain_transpose")
+    return bt
+
+
+def pretrain_workspace(S, A, b, device):
+    n = load().mobody_pretrain_workspace(S, A, b)
+    if n < 0:
+        raise _lib.MobodyError("mobody_pretrain_workspace: " + load().mobody_last_error().decode())
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+def pretrain_gather(state, action, next_state, reward, idx, start, b, out=None):
+    """idx: device int32 [7, n_idx].  Returns (xenc[7,2b,S], act[7,b,A], rew[7,b])."""
+    S, A = state.shape[1], action.shape[1]
+    dev = state.device
+    assert idx.dtype == torch.int32 and idx.dim() == 2 and idx.shape[0] == 7 and idx.is_contiguous()
+    xenc, act, rew = out or (torch.empty(7, 2 * b, S, dtype=torch.float32, device=dev),
+                             torch.empty(7, b, A, dtype=torch.float32, device=dev),
+                             torch.empty(7, b, dtype=torch.float32, device=dev))
+    check(load().mobody_pretrain_gather(ptr(state), ptr(action), ptr(next_state), ptr(reward), ptr(idx), idx.shape[1], start,
+                                        b, S, A, ptr(xenc), ptr(act), ptr(rew), cur_stream()), "mobody_pretrain_gather")
+    return xenc, act, rew
+
+
+def pretrain_grads(S, A, b, use_trg, encoder_loss_coef, blob, blob_T, xenc, act, rew, grad, loss_out, ws, noise6=None,
+                   noise7=None, seed=0, call=0, b_global=None):
+    check(load().mobody_pretrain_grads(S, A, b, b if b_global is None else b_global, int(bool(use_trg)),
+                                       float(encoder_loss_coef), ptr(blob), ptr(blob_T), ptr(xenc), ptr(act), ptr(rew),
+                                       ptr(noise6), ptr(noise7), seed, call, ptr(grad), ptr(loss_out), ptr(ws),
+                                       cur_stream()), "mobody_pretrain_grads")
+
+
+def pretrain_adam(S, A, use_trg, blob, blob_T, grad, m, v, t_main, t_za, lr, grad_scale=1.0):
+    check(load().mobody_pretrain_adam(S, A, int(bool(use_trg)), ptr(blob), ptr(blob_T), ptr(grad), ptr(m), ptr(v), t_main,
+                                      t_za, float(lr), float(grad_scale), cur_stream()), "mobody_pretrain_adam")
+
+
+def dyn_validate(blob, S, A, obs, act, next_obs, rew, use_trg, ws=None):
+    """validate(): out[0:7] per-member transition MSE, out[7:14] per-member reward MSE (device tensor)."""
+    B = obs.shape[0]
+    need = load().mobody_dyn_validate_workspace(S, A, B)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=obs.device)
+    out = torch.empty(14, dtype=torch.float32, device=obs.device)
+    check(load().mobody_dyn_validate(ptr(blob), S, A, ptr(_f32(obs)), ptr(_f32(act)), ptr(_f32(next_obs)),
+                                     ptr(_f32(rew).reshape(-1).contiguous()), B, int(bool(use_trg)), ptr(out), ptr(ws),
+                                     cur_stream()), "mobody_dyn_validate")
+    return out

@@ -89,3 +89,66 @@ def unpack_mlp(blob, in_dim, out_dim, members):
             "network.4.bias": v(L.b3, L.Np3)[:out_dim].clone(),
         })
     return out
+
+
+# ---- dynamics pre-training blob (csrc/pretrain.hip, MobodyPretrainLayout) ------------------------------------------
+PRETRAIN_NETS = (("enc", ("zs1", "zs2", "zs3")), ("tr", ("transition1", "transition2", "transition3")),
+                 ("rw", ("reward_model1", "reward_model2", "reward_model3")))
+ZA_NETS = (("off_za_src", "za_src"), ("off_za_trg", "za_trg"))
+
+
+def pack_pretrain(params, S, A, device):
+    """Reference state_dict tensors (`<layer>.weight [7,in,out]`, `.bias [7,1,out]`) -> the training blob."""
+    L = _lib.pretrain_layout(S, A)
+    g = lambda k: torch.as_tensor(params[k], dtype=torch.float32).to(device)
+    blob = torch.zeros(L.total_floats, dtype=torch.float32, device=device)
+    for nm, (l1, l2, l3) in PRETRAIN_NETS:
+        ml = getattr(L, nm)
+        members = []
+        for e in range(7):                              # EnsembleLinear stores [in, out]; pack_mlp wants nn.Linear's [out, in]
+            members.append({"network.0.weight": g(l1 + ".weight")[e].t(), "network.0.bias": g(l1 + ".bias")[e, 0],
+                            "network.2.weight": g(l2 + ".weight")[e].t(), "network.2.bias": g(l2 + ".bias")[e, 0],
+                            "network.4.weight": g(l3 + ".weight")[e].t(), "network.4.bias": g(l3 + ".bias")[e, 0]})
+        off = getattr(L, "off_" + nm)
+        blob[off:off + ml.total_floats] = pack_mlp(members, ml.in_dim, ml.out_dim, device)
+    for off_name, pre in ZA_NETS:
+        off = getattr(L, off_name)
+        W1, b1, W2, b2 = g(pre + "1.weight"), g(pre + "1.bias"), g(pre + "2.weight"), g(pre + "2.bias")
+        z = torch.zeros(7, L.za_member_floats, dtype=torch.float32, device=device)
+        z[:, L.za_w1:L.za_w1 + L.za_in * 32] = W1.reshape(7, -1)
+        z[:, L.za_b1:L.za_b1 + 32] = b1[:, 0]
+        z[:, L.za_w2:L.za_w2 + 512] = W2[:, :, :16].reshape(7, -1)          # mu half only
+        z[:, L.za_b2:L.za_b2 + 16] = b2[:, 0, :16]
+        blob[off:off + z.numel()] = z.reshape(-1)
+    return blob
+
+
+def unpack_pretrain(blob, S, A, into=None):
+    """Inverse of pack_pretrain.  Returns {name: tensor} in the reference layout; `into` (a state-dict-like mapping of
+    full-size tensors) supplies the halves the blob does not hold (logvar half of za_*2) and is updated in place."""
+    L = _lib.pretrain_layout(S, A)
+    out = {}
+    for nm, names in PRETRAIN_NETS:
+        ml = getattr(L, nm)
+        off = getattr(L, "off_" + nm)
+        ms = unpack_mlp(blob[off:off + ml.total_floats], ml.in_dim, ml.out_dim, 7)
+        for li, lname in zip((0, 2, 4), names):
+            out[lname + ".weight"] = torch.stack([m[f"network.{li}.weight"].t() for m in ms]).contiguous()
+            out[lname + ".bias"] = torch.stack([m[f"network.{li}.bias"] for m in ms]).unsqueeze(1).contiguous()
+    for off_name, pre in ZA_NETS:
+        off = getattr(L, off_name)
+        z = blob[off:off + 7 * L.za_member_floats].view(7, L.za_member_floats)
+        out[pre + "1.weight"] = z[:, L.za_w1:L.za_w1 + L.za_in * 32].reshape(7, L.za_in, 32).clone()
+        out[pre + "1.bias"] = z[:, L.za_b1:L.za_b1 + 32].reshape(7, 1, 32).clone()
+        W2mu = z[:, L.za_w2:L.za_w2 + 512].reshape(7, 32, 16)
+        b2mu = z[:, L.za_b2:L.za_b2 + 16].reshape(7, 1, 16)
+        if into is not None:
+            W2, b2 = into[pre + "2.weight"].clone(), into[pre + "2.bias"].clone()
+            W2[:, :, :16] = W2mu; b2[:, :, :16] = b2mu
+            out[pre + "2.weight"], out[pre + "2.bias"] = W2, b2
+        else:
+            out[pre + "2.weight.mu"], out[pre + "2.bias.mu"] = W2mu.clone(), b2mu.clone()
+    if into is not None:
+        for k, v in out.items():
+            into[k] = v
+    return out

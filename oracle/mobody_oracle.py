@@ -468,6 +468,94 @@ def train_step(st, batch, n_true, cfg, apply=True):
 
 
 # --------------------------------------------------------------------------- #
+# 8(f) row 1: dynamics pre-training (one optimizer step of MOBODYEnsembleDynamics.learn)
+# --------------------------------------------------------------------------- #
+
+TRAINED_LAYERS = ("zs1", "zs2", "zs3", "za_src1", "za_src2", "za_trg1", "za_trg2", "transition1", "transition2",
+                  "transition3", "reward_model1", "reward_model2", "reward_model3")
+
+
+def dyn_learn_losses(p, obs, act, next_obs, rew, noise, use_trg, encoder_loss_coef=1.0):
+    """The loss of one `learn()` batch, mobody_dynamics.py:594-653 (no_vae=0, latent_reward=0, inverse_sep_reward_loss=0):
+
+      encoder_loss (:300-330)   100 * [sum_e mean_{b,d}(dec(z1) - s)^2 + ... (dec(z2) - s')^2]
+                                + 0.05 * KL(s) + 0.05 * KL(s')                       (get_kl_loss :332-335)
+                                + sum_e mean_{b,16}((z3 + za(z3,a)) - z4)^2          (z4 = encode_state(s') under no_grad)
+      transition_loss (:337-347) sum_e mean_{b,d}(forward(s,a) - s')^2               (state sample z5)
+      reward_loss (:349-384)    [sum_e mean_b (r(s,a,fake) - r)^2 + sum_e mean_b (r(s,a,s') - r)^2] * (1 if trg else 0.01),
+                                fake = mean6 + eps7 * std_e(mean6) with the gradient flowing through mean6 AND the std
+      loss = transition + (5 if trg else 1) * encoder_loss_coef * encoder_loss + reward_loss          (:619-639)
+
+    obs/next_obs [E,b,S], act [E,b,A], rew [E,b,1] are per-member bootstrap rows.  `noise` = the seven randn_like draws
+    in the reference's order: z1(s), z2(s'), z3(s), z4(s'), z5(s), z6(s) as [E,b,16] and eps7 [E,b,S]
+    (reparameterize, mobody_module.py:237-243: z = mu + eps * exp(0.5 * logvar) in training mode).
+    Returns (loss, transition_loss, encoder_loss, recon_loss, kl_loss)."""
+    s, a, s2, r = T(obs), T(act), T(next_obs), T(rew)
+    n = [T(x) for x in noise]
+    pre = "za_trg" if use_trg else "za_src"
+
+    def enc(x, eps):                                                  # encode_state :217-225
+        mu, lv = dyn_encode_state(p, x)
+        return mu + eps * torch.exp(0.5 * lv), mu, lv
+
+    def za(zs):                                                       # encode_*_action :245-271
+        g = swish(_el(p, pre + "1", torch.cat([zs, a], -1)))
+        return _el(p, pre + "2", g)[..., :L]
+
+    kl = lambda mu, lv: 0.05 * (-0.5 * (1 + lv - mu.pow(2) - lv.exp()).mean(dim=(1, 2))).sum()
+    z1, mu1, lv1 = enc(s, n[0])
+    z2, mu2, lv2 = enc(s2, n[1])
+    recon = ((dyn_decode_transition(p, z1) - s) ** 2).mean(dim=(1, 2)).sum() + \
+            ((dyn_decode_transition(p, z2) - s2) ** 2).mean(dim=(1, 2)).sum()
+    kl_loss = kl(mu1, lv1) + kl(mu2, lv2)
+    z3, _, _ = enc(s, n[2])
+    with torch.no_grad():
+        z4, _, _ = enc(s2, n[3])
+    enc_loss = 100 * recon + kl_loss + (((z3 + za(z3)) - z4) ** 2).mean(dim=(1, 2)).sum()
+    z5, _, _ = enc(s, n[4])
+    trans = ((dyn_decode_transition(p, z5 + za(z5)) - s2) ** 2).mean(dim=(1, 2)).sum()
+    loss = trans + (5 if use_trg else 1) * encoder_loss_coef * enc_loss
+    z6, _, _ = enc(s, n[5])
+    mean6 = dyn_decode_transition(p, z6 + za(z6))
+    fake = mean6 + n[6] * torch.std(mean6, dim=0, keepdim=True)
+    rl = ((dyn_reward(p, s, a, fake)[0] - r) ** 2).mean(dim=(1, 2)).sum() + \
+         ((dyn_reward(p, s, a, s2)[0] - r) ** 2).mean(dim=(1, 2)).sum()
+    loss = loss + (rl if use_trg else 0.01 * rl)
+    return loss, trans, enc_loss, recon, kl_loss
+
+
+class DynTrainState:
+    """Live dynamics parameters (the 13 trained EnsembleLinear layers) with torch.optim.Adam state PER PARAMETER:
+    a parameter whose gradient is None in a step (za_trg* on source batches, za_src* on target ones) is skipped by
+    Adam and keeps its own step count (train_mobody.py:801-804 hands every parameter to one Adam)."""
+
+    def __init__(self, params, lr=1e-3):
+        self.p = {k: T(v).clone() for k, v in params.items() if k.split(".")[0] in TRAINED_LAYERS and
+                  k.split(".")[1] in ("weight", "bias")}
+        self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.t = {k: 0 for k in self.p}
+        self.lr = lr
+
+
+def dyn_learn_step(st, obs, act, next_obs, rew, noise, use_trg, encoder_loss_coef=1.0, apply=True):
+    """zero_grad -> loss.backward -> Adam.step of one learn() batch (mobody_dynamics.py:641-643).
+    Returns dict(losses=(5 floats), grads={name: tensor or None})."""
+    pr = {k: v.detach().clone().requires_grad_(True) for k, v in st.p.items()}
+    losses = dyn_learn_losses(pr, obs, act, next_obs, rew, noise, use_trg, encoder_loss_coef)
+    names = list(pr)
+    gs = torch.autograd.grad(losses[0], [pr[k] for k in names], allow_unused=True)
+    grads = dict(zip(names, gs))
+    if apply:
+        for k, g in grads.items():
+            if g is None:
+                continue
+            st.t[k] += 1
+            adam_update(st.p[k], g, st.m[k], st.v[k], st.t[k], st.lr)
+    return dict(losses=tuple(float(x.detach()) for x in losses), grads=grads)
+
+
+# --------------------------------------------------------------------------- #
 # A15: DARA reward penalty with the reference's softmax quirks
 # --------------------------------------------------------------------------- #
 

@@ -78,3 +78,20 @@ def checksum(params):
         v = np.asarray(params[k], np.float64)
         tot += float(v.sum()) + 3.0 * float(np.abs(v).sum()) + 7.0 * float((v * v).sum())
     return tot
+
+
+def pretrain_batch(seed, b, S, A):
+    """Per-member bootstrap rows of one dynamics pre-training batch: obs[E,b,S], act[E,b,A], next_obs[E,b,S], rew[E,b,1]
+    (mobody_dynamics.py:594-612 slices `train_obss[:, k*bs:(k+1)*bs]` of the bootstrapped arrays)."""
+    rng = np.random.default_rng(seed)
+    s = np.stack([walker_like_obs(rng, b, S) for _ in range(E)])
+    a = rng.uniform(-1, 1, (E, b, A)).astype(np.float32)
+    s2 = (s + 0.05 * rng.standard_normal((E, b, S))).astype(np.float32)
+    r = rng.standard_normal((E, b, 1)).astype(np.float32)
+    return s, a, s2, r
+
+
+def noise_stream(seed):
+    """The numpy generator make_golden.NoiseTap drew the reparameterisation / fake-next-state noise from:
+    call `.standard_normal(shape).astype(float32)` in the reference's order."""
+    return np.random.default_rng(seed)

@@ -555,7 +555,78 @@ def g11():
         save(f"g11_refresh_{tag}", **out)
 
 
+# -------------------------------------------------------------------------- G12
+def sub101(x):
+    """Coarser thinning for the pre-training fixtures (the float64 sum / sum of squares of every gradient tensor is
+    stored next to it, so the whole tensor is still pinned)."""
+    f = np.asarray(x).reshape(-1)
+    return f[::101].copy() if f.size > 65536 else f[::17].copy() if f.size > 256 else f.copy()
+
+
+class NoiseTap:
+    """Every torch.randn_like (reparameterisation noise mobody_module.py:239-240, fake-next-state noise
+    mobody_dynamics.py:353) is replaced by the next draw of numpy default_rng(seed): tests regenerate the identical
+    stream from the seed (gen_inputs.noise_stream), so no noise is stored."""
+
+    def __init__(self, seed):
+        self.rng, self.shapes = np.random.default_rng(seed), []
+
+    def __enter__(self):
+        self._r = torch.randn_like
+
+        def randn_like(x, **k):
+            self.shapes.append(tuple(x.shape))
+            return torch.from_numpy(self.rng.standard_normal(tuple(x.shape)).astype(np.float32))
+
+        torch.randn_like = randn_like
+        return self
+
+    def __exit__(self, *a):
+        torch.randn_like = self._r
+
+
+PRE_CFG = dict(DYN_CFG, no_vae=0, inverse_sep_reward_loss=0, train_together=0, train_with_src_threshold=1)
+
+
+def make_dyn_trainer(S, A, seed, lr=1e-3):
+    m, p = load_dyn(S, A, seed, 0, 0.85)
+    m.config = dict(PRE_CFG)
+    opt = torch.optim.Adam(m.parameters(), lr=lr)                 # train_mobody.py:801-804
+    dyn = MOBODYEnsembleDynamics(dict(PRE_CFG), m, opt, None, get_termination_fn("walker2d-medium-v2"), penalty_coef=0.1)
+    dyn.total_steps = 0
+    return dyn, m, p
+
+
+def g12():
+    """Dynamics pre-training, one optimizer step per `learn()` call (mobody_dynamics.py:594-653 with encoder_loss
+    :300-330, transition_loss :337-347, reward_loss :349-384): the call sequence src, trg, src, trg pins the losses,
+    every gradient, the per-parameter Adam step counts (za_src* only steps on source batches, za_trg* on target ones,
+    decoders and saved_* never) and the post-step parameters."""
+    for tag, S, A, b, seed in (("walker", 17, 6, 24, 211), ("pen", 45, 24, 20, 213)):
+        dyn, m, p = make_dyn_trainer(S, A, seed)
+        out = dict(S=S, A=A, b=b, seed=seed, alive_val=0.85, wsum=gi.checksum(p), noise_seed=1200 + seed, lr=1e-3)
+        with NoiseTap(1200 + seed) as tap, CudaAlias():
+            for step, use_trg in enumerate((False, True, False, True)):
+                rows = gi.pretrain_batch(3000 + 10 * seed + step, b, S, A)       # per-member rows [7,b,.]
+                res = dyn.learn(use_trg, *[torch.from_numpy(x) for x in rows], b, 0.01)
+                out[f"s{step}_losses"] = np.array(res, np.float64)               # loss, transition, encoder, recon, kl
+                for k, v in m.named_parameters():
+                    if v.grad is not None and not k.startswith(("max_", "min_", "elites")):
+                        g = v.grad.numpy()
+                        out[f"s{step}_g::{k}"] = sub101(g)
+                        out[f"s{step}_gsum::{k}"] = np.array([g.astype(np.float64).sum(), (g.astype(np.float64) ** 2).sum()])
+                    if ".saved_" not in k and not k.startswith(("max_", "min_", "elites")):
+                        out[f"s{step}_p::{k}"] = sub101(v.detach().numpy())
+                out[f"s{step}_has_grad"] = np.array(sorted(k for k, v in m.named_parameters() if v.grad is not None))
+        out["noise_shapes"] = np.array([",".join(map(str, sh)) for sh in tap.shapes])
+        st = dyn.optim.state_dict()["state"]
+        names = [k for k, _ in m.named_parameters()]
+        out["adam_steps"] = np.array([f"{names[i]}={int(float(v['step']))}" for i, v in st.items()])
+        print("pretrain", tag, [out[f"s{k}_losses"][0] for k in range(4)], "noise calls", len(tap.shapes))
+        save(f"g12_pretrain_{tag}", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9", "g9b", "g11"]
+    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12"]
     for w in which:
         globals()[w]()

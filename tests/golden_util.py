@@ -18,6 +18,12 @@ def sub(x):
     return f[::13].copy() if f.size > 4096 else f.copy()
 
 
+def sub101(x):
+    """Same thinning rule as make_golden.sub101 (pre-training fixtures)."""
+    f = np.asarray(x).reshape(-1)
+    return f[::101].copy() if f.size > 65536 else f[::17].copy() if f.size > 256 else f.copy()
+
+
 def dyn_params_for(g):
     """Regenerate the dynamics weights a g234/g6 fixture was produced with and verify the checksum."""
     seed = int(g["dyn_seed"]) if "dyn_seed" in g else int(g["seed"])

@@ -1,0 +1,199 @@
+"""Dynamics pre-training on the GPU (csrc/pretrain.hip through the C ABI) against the reference's golden vectors
+(tests/golden/g12_pretrain_*.npz, produced by make_golden.g12 from MOBODYEnsembleDynamics.learn) and the oracle.
+
+Tolerances (north_star: 1e-5 fp32):
+  * losses: 2e-5 relative (sums of ~1e4 squared residuals in a different order than torch's);
+  * gradients: |hip - ref| <= 1e-5 * max|g| of the tensor's sub-network + 1e-5 |g|  (the three sub-networks' gradient
+    scales differ by orders of magnitude -- 100x reconstruction weight on the encoder/decoder, 0.01x on the source
+    domain's reward head -- so each is judged against its own scale);
+  * parameters after Adam: same rule as tests/test_hip_train.py (99.5 % within 1e-5, all within 0.1 * lr).
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import mobody_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SUBNET = dict(zs="enc", tr="tr", re="rw", za="za")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def close(a, b, rtol=1e-5, atol=1e-5):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a.astype(np.float64), b.astype(np.float64), rtol=rtol, atol=atol)
+
+
+def noise7(rng, b, S):
+    return [rng.standard_normal((7, b, 16)).astype(np.float32) for _ in range(6)] + \
+           [rng.standard_normal((7, b, S)).astype(np.float32)]
+
+
+class Trainer:
+    """Minimal driver of the pre-training entry points of the C ABI."""
+
+    def __init__(self, p, S, A, b, dev, lr=1e-3):
+        from mobody_amd import ops, packing
+        self.ops, self.packing, self.S, self.A, self.b, self.dev, self.lr = ops, packing, S, A, b, dev, lr
+        self.blob = packing.pack_pretrain(p, S, A, dev)
+        self.blob_T = ops.pretrain_transpose(self.blob, S, A)
+        self.grad, self.m, self.v = (torch.zeros_like(self.blob) for _ in range(3))
+        self.loss = torch.zeros(5, device=dev)
+        self.ws = ops.pretrain_workspace(S, A, b, dev)
+        self.t_main, self.t_za = 0, {False: 0, True: 0}
+        self.zero2 = {k: torch.zeros(7, 32, 32, device=dev) for k in ("za_src2.weight", "za_trg2.weight")}
+        self.zero2.update({k: torch.zeros(7, 1, 32, device=dev) for k in ("za_src2.bias", "za_trg2.bias")})
+
+    def grads(self, rows, noise, use_trg, b_global=None):
+        td = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.dev)
+        s, a, s2, r = rows
+        xenc = td(np.concatenate([s, s2], 1)); act = td(a); rew = td(r[..., 0])
+        n6 = td(np.stack(noise[:6])); n7 = td(noise[6])
+        self.ops.pretrain_grads(self.S, self.A, s.shape[1], use_trg, 1.0, self.blob, self.blob_T, xenc, act, rew, self.grad,
+                                self.loss, self.ws, noise6=n6, noise7=n7, b_global=b_global)
+        torch.cuda.synchronize()
+        return self.loss.cpu().numpy().copy()
+
+    def apply(self, use_trg):
+        self.t_main += 1; self.t_za[use_trg] += 1
+        self.ops.pretrain_adam(self.S, self.A, use_trg, self.blob, self.blob_T, self.grad, self.m, self.v, self.t_main,
+                               self.t_za[use_trg], self.lr)
+
+    def unpack(self, blob, full_za2=None):
+        into = {k: v.clone() for k, v in (full_za2 or self.zero2).items()}
+        return self.packing.unpack_pretrain(blob, self.S, self.A, into=into)
+
+
+@pytest.mark.parametrize("tag", ["walker", "pen"])
+def test_pretrain_steps_vs_reference_golden(tag, dev):
+    from test_hip_train import params_close
+    g = gu.load(f"g12_pretrain_{tag}")
+    S, A, b, seed = int(g["S"]), int(g["A"]), int(g["b"]), int(g["seed"])
+    p = gu.dyn_params_for(g)
+    tr = Trainer(p, S, A, b, dev, lr=float(g["lr"]))
+    full2 = {k: torch.from_numpy(p[k]).to(dev) for k in ("za_src2.weight", "za_trg2.weight", "za_src2.bias", "za_trg2.bias")}
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    for step, use_trg in enumerate((False, True, False, True)):
+        rows = gu.gi.pretrain_batch(3000 + 10 * seed + step, b, S, A)
+        losses = tr.grads(rows, noise7(rng, b, S), use_trg)
+        close(losses, g[f"s{step}_losses"], rtol=2e-5, atol=1e-6)
+        has = [str(x) for x in g[f"s{step}_has_grad"]]
+        skip = "za_trg" if not use_trg else "za_src"
+        assert not any(k.startswith(skip) for k in has)                 # the other domain's action encoder: .grad is None
+        got = tr.unpack(tr.grad)
+        scale = {}
+        for k in has:
+            sn = SUBNET[k[:2]]
+            scale[sn] = max(scale.get(sn, 0.0), float(np.abs(g[f"s{step}_g::{k}"]).max()))
+        for k in has:
+            want = g[f"s{step}_g::{k}"]
+            close(gu.sub101(got[k].cpu().numpy()), want, rtol=1e-5, atol=1e-5 * scale[SUBNET[k[:2]]])
+            s64 = g[f"s{step}_gsum::{k}"]                               # whole-tensor pins: sum and sum of squares
+            gk = got[k].double()
+            close(float((gk * gk).sum()), s64[1], rtol=1e-4, atol=1e-30)
+        tr.apply(use_trg)
+        cur = tr.unpack(tr.blob, full2)
+        for k in cur:
+            params_close(gu.sub101(cur[k].cpu().numpy()), g[f"s{step}_p::{k}"], tr.lr)
+    want_t = {x.split("=")[0]: int(x.split("=")[1]) for x in g["adam_steps"]}
+    assert want_t["zs1.weight"] == tr.t_main and want_t["za_src1.weight"] == tr.t_za[False] and want_t["za_trg2.bias"] == tr.t_za[True]
+
+
+@pytest.mark.parametrize("S,A,b", [(17, 6, 1), (17, 6, 33), (17, 6, 256), (111, 8, 40), (45, 24, 65)])
+def test_pretrain_grads_vs_oracle_shapes(S, A, b, dev):
+    """Ragged / full batches and the ant / pen shapes against the oracle's autograd (same noise), source and target step."""
+    p = gu.gi.dyn_params(5, S, A)
+    tr = Trainer(p, S, A, b, dev)
+    rng = np.random.default_rng(b)
+    for use_trg in (False, True):
+        rows = gu.gi.pretrain_batch(77 + b, b, S, A)
+        nz = noise7(rng, b, S)
+        st = O.DynTrainState(p)
+        want = O.dyn_learn_step(st, *rows, nz, use_trg, apply=False)
+        tr.grad.zero_()
+        losses = tr.grads(rows, nz, use_trg)
+        close(losses, np.array(want["losses"]), rtol=2e-5, atol=1e-6)
+        got = tr.unpack(tr.grad)
+        scale = {}
+        for k, v in want["grads"].items():
+            if v is not None:
+                scale[SUBNET[k[:2]]] = max(scale.get(SUBNET[k[:2]], 0.0), float(v.abs().max()))
+        for k, v in want["grads"].items():
+            if v is None:
+                assert float(got[k].abs().max()) == 0.0, k             # untouched region stays zero
+                continue
+            close(got[k], v, rtol=1e-5, atol=1e-5 * scale[SUBNET[k[:2]]])
+
+
+def test_pretrain_data_parallel_shards_sum_to_full_batch(dev):
+    """Two ranks' shares (b rows each, b_global = 2b) add up to the gradient and losses of the 2b-row batch whenever the
+    ensemble-coupled term is row-local (it is: the std runs over members, not rows)."""
+    S, A, b = 17, 6, 48
+    p = gu.gi.dyn_params(9, S, A)
+    rows = gu.gi.pretrain_batch(5, 2 * b, S, A)
+    rng = np.random.default_rng(0)
+    nz = noise7(rng, 2 * b, S)
+    full = Trainer(p, S, A, 2 * b, dev)
+    lf = full.grads(rows, nz, True)
+    acc, lsum = torch.zeros_like(full.grad), np.zeros(5)
+    for h in (0, 1):
+        sl = slice(h * b, (h + 1) * b)
+        sh = Trainer(p, S, A, b, dev)
+        lsum += sh.grads(tuple(x[:, sl] for x in rows), [x[:, sl] for x in nz], True, b_global=2 * b)
+        acc += sh.grad
+    close(lsum, lf, rtol=1e-5, atol=1e-6)
+    scale = float(full.grad.abs().max())
+    close(acc, full.grad, rtol=1e-5, atol=2e-6 * scale)
+
+
+def test_pretrain_gather_and_device_noise(dev):
+    """Bootstrap gather == fancy indexing; with noise=None the kernels draw Philox streams 16..22 themselves and the
+    result equals the explicit-noise call fed with the CPU twin of those streams."""
+    from mobody_amd import ops
+    S, A, b, n = 17, 6, 40, 300
+    s, a, s2, r, _ = gu.gi.batch(3, n, S, A)
+    td = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    idx = np.random.default_rng(1).integers(0, n, (7, 120)).astype(np.int32)
+    xenc, act, rew = ops.pretrain_gather(td(s), td(a), td(s2), td(r), td(idx), 37, b)
+    sel = idx[:, 37:37 + b]
+    assert torch.equal(xenc[:, :b].cpu(), torch.from_numpy(s[sel])) and torch.equal(xenc[:, b:].cpu(), torch.from_numpy(s2[sel]))
+    assert torch.equal(act.cpu(), torch.from_numpy(a[sel])) and torch.equal(rew.cpu(), torch.from_numpy(r[sel][..., 0]))
+    p = gu.gi.dyn_params(5, S, A)
+    tr = Trainer(p, S, A, b, dev)
+    ops.pretrain_grads(S, A, b, True, 1.0, tr.blob, tr.blob_T, xenc, act, rew, tr.grad, tr.loss, tr.ws, seed=11, call=4)
+    torch.cuda.synchronize()
+    l_dev, g_dev = tr.loss.cpu().numpy().copy(), tr.grad.clone()
+    nz = [O.rng_normal(11, 16 + k, 4, 7 * b * 16).reshape(7, b, 16) for k in range(6)] + \
+         [O.rng_normal(11, 22, 4, 7 * b * S).reshape(7, b, S)]
+    tr.grad.zero_()
+    l_exp = tr.grads((s[sel], a[sel], s2[sel], r[sel]), nz, True)
+    close(l_dev, l_exp, rtol=2e-5, atol=1e-6)
+    close(g_dev, tr.grad, rtol=1e-4, atol=2e-5 * float(tr.grad.abs().max()))
+
+
+def test_dyn_validate_vs_oracle(dev):
+    """validate() (mobody_dynamics.py:1113-1140): per-member transition and reward MSE on a holdout set."""
+    from mobody_amd import ops, packing
+    S, A, B = 17, 6, 137
+    p = gu.gi.dyn_params(5, S, A)
+    s, a, s2, r, _ = gu.gi.batch(8, B, S, A)
+    blob = packing.pack_dynamics(p, S, A, dev)
+    td = lambda x: torch.from_numpy(x).to(dev)
+    for use_trg in (True, False):
+        out = ops.dyn_validate(blob, S, A, td(s), td(a), td(s2), td(r), use_trg).cpu().numpy()
+        pt = O.to_torch(p)
+        with torch.no_grad():
+            mean, _, _ = O.dyn_forward(pt, O.T(s), O.T(a), use_trg)
+            tl = ((mean - O.T(s2)) ** 2).mean(dim=(1, 2))
+            pr, _ = O.dyn_reward(pt, O.T(s).unsqueeze(0).repeat(7, 1, 1), O.T(a).unsqueeze(0).repeat(7, 1, 1), mean)
+            rl = ((pr - O.T(r)) ** 2).mean(dim=(1, 2))
+        close(out[:7], tl, rtol=1e-5, atol=1e-7)
+        close(out[7:], rl, rtol=1e-5, atol=1e-7)

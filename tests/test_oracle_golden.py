@@ -270,3 +270,37 @@ def test_g9b_dara_penalize_fake():
     close(float(loss.detach()), float(g["loss_sa"]) + float(g["loss_sas"]), rtol=1e-5)
     for (k, _), gr in zip(pr.items(), torch.autograd.grad(loss, list(pr.values()))):
         close(gu.sub(gr.numpy()), g["cls_g::" + k], rtol=2e-4, atol=2e-7)
+
+
+def _noise7(rng, b, S):
+    return [rng.standard_normal((7, b, 16)).astype(np.float32) for _ in range(6)] + \
+           [rng.standard_normal((7, b, S)).astype(np.float32)]
+
+
+@pytest.mark.parametrize("tag", ["walker", "pen"])
+def test_g12_dynamics_pretraining_steps(tag):
+    """Four learn() steps src, trg, src, trg against the reference: losses, every gradient (thinned values + full-tensor
+    float64 sums), which parameters receive a gradient, per-parameter Adam step counts, post-step parameters."""
+    g = gu.load(f"g12_pretrain_{tag}")
+    S, A, b, seed = int(g["S"]), int(g["A"]), int(g["b"]), int(g["seed"])
+    p = gu.dyn_params_for(g)
+    st = O.DynTrainState(p, lr=float(g["lr"]))
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    shapes = [tuple(int(x) for x in s.split(",")) for s in g["noise_shapes"]]
+    assert shapes[:7] == [(7, b, 16)] * 6 + [(7, b, S)]            # the order of the reference's randn_like calls
+    for step, use_trg in enumerate((False, True, False, True)):
+        rows = gu.gi.pretrain_batch(3000 + 10 * seed + step, b, S, A)
+        out = O.dyn_learn_step(st, *rows, _noise7(rng, b, S), use_trg)
+        close(np.array(out["losses"]), g[f"s{step}_losses"], rtol=2e-5, atol=1e-6)
+        has = sorted(k for k, v in out["grads"].items() if v is not None)
+        assert has == [str(x) for x in g[f"s{step}_has_grad"]]
+        scale = max(float(np.abs(g[k]).max()) for k in g if k.startswith(f"s{step}_g::"))
+        for k in has:
+            gr = out["grads"][k].numpy()
+            close(gu.sub101(gr), g[f"s{step}_g::{k}"], rtol=1e-4, atol=1e-5 * scale)
+            s64 = g[f"s{step}_gsum::{k}"]
+            close((gr.astype(np.float64) ** 2).sum(), s64[1], rtol=1e-4, atol=1e-12)
+        for k, v in st.p.items():
+            close(gu.sub101(v.numpy()), g[f"s{step}_p::{k}"], rtol=1e-5, atol=2e-6)
+    want = dict(x.split("=") for x in g["adam_steps"])
+    assert {k: int(v) for k, v in want.items()} == st.t
