@@ -61,7 +61,10 @@ class MOBODYEnsembleDynamics(object):
         self.rng, self.seed = rng, int(seed)
         self._calls = 0
         self.noise_fn = None          # optional hook: noise_fn((7, B, S)) -> unit normals (tests)
+        self.train_noise_fn = None    # optional hook: b -> (noise6[6,7,b,16], noise7[7,b,S]) device tensors (tests)
         self._ws = None
+        self._pre_ws, self._train_calls = None, 0
+        self._pre_loss = torch.zeros(5, dtype=torch.float32, device=model.device)
         task_id = getattr(terminal_fn, "task_id", None)
         if task_id is None:
             raise TypeError("terminal_fn must come from mobody_amd.algo.mb_utils.terminal_funs.get_termination_fn "
@@ -108,9 +111,204 @@ class MOBODYEnsembleDynamics(object):
         return {"obs_mse": dist.mean(), "obs_mse_individual": dist,
                 "reward_mse": torch.mean((rew - r["reward"].reshape(-1)) ** 2), "penalty": r["penalty"]}
 
-    def train(self, *a, **k):
-        raise NotImplementedError("dynamics pre-training (mobody_dynamics.py:731-978) is the first 'next' row of "
-                                  "SURVEY 8(f); load a pretrained dynamics with .load(dir)")
+    # ------------------------------------------------------------------ pre-training (mobody_dynamics.py:594-653,731-978,1113-1156)
+    def _check_pretrain_config(self):
+        cfg = self.config
+        if cfg.get("no_vae") or cfg.get("inverse_sep_reward_loss") or cfg.get("latent_reward") or cfg.get("train_together"):
+            raise NotImplementedError("no_vae / inverse_sep_reward_loss / latent_reward / train_together are ablations "
+                                      "outside the accelerated pre-training path (reference defaults are 0)")
+        if cfg.get("train_with_src_threshold", 1) != 1:
+            raise NotImplementedError("train_with_src_threshold != 1 (data_augmentation) is outside the accelerated path")
+
+    def _lr(self):
+        o = self.optim                                    # torch.optim.Adam(model.parameters(), lr=dynamics_lr) in the reference
+        if o is not None and getattr(o, "param_groups", None):
+            return float(o.param_groups[0]["lr"])
+        return float(getattr(o, "lr", None) or self.config.get("dynamics_lr", 1e-3))
+
+    def _world(self):
+        d = torch.distributed
+        return (d.get_world_size(), d.get_rank()) if d.is_available() and d.is_initialized() else (1, 0)
+
+    def _learn_batch(self, use_trg, xenc, act, rew, b, b_global):
+        """One optimizer step on the rows already laid out as the kernels want them (zero_grad, backward, Adam.step)."""
+        m = self.model
+        st = m.train_state()
+        S, A = m.obs_dim, m.action_dim
+        if self._pre_ws is None or self._pre_ws[0] != b:
+            self._pre_ws = (b, ops.pretrain_workspace(S, A, max(b, 1), m.device))
+        self._train_calls += 1
+        n6 = n7 = None
+        if self.train_noise_fn is not None:
+            n6, n7 = self.train_noise_fn(b)
+        world, _ = self._world()
+        if b > 0:
+            ops.pretrain_grads(S, A, b, use_trg, self.encoder_loss_coef, st["blob"], st["blob_T"], xenc, act, rew, st["grad"],
+                               self._pre_loss, self._pre_ws[1], noise6=n6, noise7=n7,
+                               seed=(self.seed + 77 + dp.rank_salt()) & 0xFFFFFFFF, call=self._train_calls, b_global=b_global)
+        else:                                             # data parallel: this rank has no row of a ragged last batch
+            st["grad"].zero_(); self._pre_loss.zero_()
+        if world > 1:
+            torch.distributed.all_reduce(st["grad"])      # one 6.5 MB message per step (SURVEY 8e)
+            torch.distributed.all_reduce(self._pre_loss)
+        st["t_main"] += 1; st["t_za"][bool(use_trg)] += 1
+        ops.pretrain_adam(S, A, use_trg, st["blob"], st["blob_T"], st["grad"], st["m"], st["v"], st["t_main"],
+                          st["t_za"][bool(use_trg)], self._lr())
+        m.mark_trained()
+        return self._pre_loss
+
+    def _learn_loop(self, n, batch_size, step):
+        """learn()'s batch loop (:604-650): `step(start, rows)` runs one batch and returns the device loss vector; the
+        five reported numbers are the means over batches, fetched once per call."""
+        self.model.training = True
+        acc = torch.zeros(5, dtype=torch.float32, device=self.model.device)
+        n_batch = int(np.ceil(n / batch_size))
+        for k in range(n_batch):
+            self.total_steps = getattr(self, "total_steps", 0) + 1
+            acc += step(k * batch_size, min(batch_size, n - k * batch_size))
+        return tuple(float(x) for x in (acc / max(n_batch, 1)).tolist())
+
+    def _shard(self, start, rows):
+        """Rows of one batch owned by this rank (data parallel: contiguous slices, b_global = rows)."""
+        world, rank = self._world()
+        lo, hi = rows * rank // world, rows * (rank + 1) // world
+        return start + lo, hi - lo
+
+    def learn(self, use_trg_data, train_obss, train_actions, train_next_obss, train_rewards, batch_size, logvar_loss_coef,
+              trg_transition=None):
+        """mobody_dynamics.py:594-653: one pass over the per-member rows `[7, n, .]` in batches of `batch_size`.
+        Returns (mean loss, mean transition_loss, mean encoder_loss, mean recon_loss, mean kl_loss)."""
+        self._check_pretrain_config()
+        dev = self.model.device
+        f = lambda x: torch.as_tensor(x, dtype=torch.float32).to(dev)
+        s, a, s2, r = f(train_obss), f(train_actions), f(train_next_obss), f(train_rewards).reshape(7, -1)
+
+        def step(start, rows):
+            lo, b = self._shard(start, rows)
+            sl = slice(lo, lo + b)
+            xenc = torch.cat([s[:, sl], s2[:, sl]], 1).contiguous()
+            return self._learn_batch(use_trg_data, xenc, a[:, sl].contiguous(), r[:, sl].contiguous(), b, rows)
+
+        return self._learn_loop(s.shape[1], batch_size, step)
+
+    def _learn_indexed(self, use_trg, data, idx, batch_size):
+        """learn() on a device-resident data set with a [7, n] bootstrap index matrix: the batch rows are gathered by a
+        kernel straight into the layout the forward pass reads (the reference gathers [7, n, .] copies on the host every
+        epoch and ships each batch over PCIe, :604-612)."""
+        def step(start, rows):
+            lo, b = self._shard(start, rows)
+            if b == 0:
+                return self._learn_batch(use_trg, None, None, None, 0, rows)
+            xenc, act, rew = ops.pretrain_gather(data[0], data[1], data[2], data[3], idx, lo, b)
+            return self._learn_batch(use_trg, xenc, act, rew, b, rows)
+
+        return self._learn_loop(idx.shape[1], batch_size, step)
+
+    @torch.no_grad()
+    def validate(self, use_trg_data, holdout_obss, holdout_actions, holdout_next_obss, holdout_rewards):
+        """mobody_dynamics.py:1113-1140 -> (val_transition_loss, val_encode_loss), two lists of 7 floats."""
+        m = self.model
+        m.training = False
+        m.inference()
+        f = lambda x: torch.as_tensor(x, dtype=torch.float32).to(m.device).contiguous()
+        out = ops.dyn_validate(m.packed(), m.obs_dim, m.action_dim, f(holdout_obss), f(holdout_actions), f(holdout_next_obss),
+                               f(holdout_rewards), use_trg_data).cpu().numpy()
+        m.uninference()
+        return list(out[:7]), list(out[7:])
+
+    def select_elites(self, metrics):
+        """:1142-1146."""
+        pairs = sorted([(metric, index) for metric, index in zip(metrics, range(len(metrics)))], key=lambda x: x[0])
+        return [pairs[i][1] for i in range(self.model.num_elites)]
+
+    def shuffle_rows(self, arr):
+        """:656-658 (NumPy global stream): an independent permutation of every member's bootstrap indices."""
+        if self.rng == "numpy":
+            a = arr.cpu().numpy()
+            idxes = np.argsort(np.random.uniform(size=a.shape), axis=-1)
+            return torch.from_numpy(a[np.arange(a.shape[0])[:, None], idxes]).to(arr.device)
+        return torch.gather(arr, 1, torch.argsort(torch.rand(arr.shape, device=arr.device), dim=1))
+
+    def train(self, src_data, trg_data, max_epochs=None, max_epochs_since_update=5, batch_size=256, holdout_ratio=0.2,
+              logvar_loss_coef=0.01, writer=None, buffer=None):
+        """mobody_dynamics.py:731-978 (train_together=0): holdout split, bootstrap indices, per epoch one pass over the
+        source rows and three over the target rows, validation, per-member early stopping on the TARGET holdout loss
+        (saved copies refreshed on > 1 % improvement), finally elites = the num_elites best members and load_save().
+        Index streams follow the reference (torch CPU generator for random_split / randint, NumPy for shuffle_rows)
+        when rng == 'numpy'."""
+        self._check_pretrain_config()
+        m = self.model
+        dev = m.device
+        self.src_replay_buffer = src_data
+        self.total_steps = 0
+        f = lambda x, c: torch.as_tensor(x, dtype=torch.float32).reshape(len(x), c).to(dev)
+        S, A = m.obs_dim, m.action_dim
+        src = [f(src_data[0], S), f(src_data[1], A), f(src_data[2], S), f(src_data[3], 1)]
+        trg = [f(trg_data[0], S), f(trg_data[1], A), f(trg_data[2], S), f(trg_data[3], 1)]
+        n_src, n_trg = src[0].shape[0], trg[0].shape[0]
+        src_hold = min(int(n_src * holdout_ratio), 1000)                                    # :762-763
+        trg_hold = min(int(n_trg * holdout_ratio), 500)
+        split = torch.utils.data.random_split
+        s_tr, s_ho = split(range(n_src), (n_src - src_hold, src_hold))                      # :765-769
+        t_tr, t_ho = split(range(n_trg), (n_trg - trg_hold, trg_hold))
+        world, _ = self._world()
+
+        def bc(t):                                        # data parallel: every rank follows rank 0's index streams
+            if world > 1:
+                torch.distributed.broadcast(t, 0)
+            return t
+
+        ix = lambda sp: bc(torch.as_tensor(sp.indices, dtype=torch.long, device=dev))
+        src_tr = [x[ix(s_tr)].contiguous() for x in src]; src_ho = [x[ix(s_ho)].contiguous() for x in src]
+        trg_tr = [x[ix(t_tr)].contiguous() for x in trg]; trg_ho = [x[ix(t_ho)].contiguous() for x in trg]
+        self.obs_scaler.fit(None)                                                           # identity (Q4)
+        n_s, n_t = n_src - src_hold, n_trg - trg_hold
+        E = m.num_ensemble
+        trg_holdout_losses = [1e10 for _ in range(E)]
+        src_idx = bc(torch.randint(n_s, size=[E, n_s]).to(device=dev, dtype=torch.int32))   # :826-827 (CPU generator)
+        trg_idx = bc(torch.randint(n_t, size=[E, n_t]).to(device=dev, dtype=torch.int32))
+        epoch, cnt = 0, 0
+        self.history = []
+        while True:
+            epoch += 1
+            self.epoch = epoch
+            src_stats = self._learn_indexed(False, src_tr, src_idx.contiguous(), batch_size)              # :873-878
+            src_val, _ = self.validate(False, *src_ho)
+            src_holdout_loss = float(np.sort(src_val)[:m.num_elites].mean())
+            for _ in range(3):                                                              # :897-907
+                trg_stats = self._learn_indexed(True, trg_tr, trg_idx.contiguous(), batch_size)
+            trg_val, trg_enc = self.validate(True, *trg_ho)
+            trg_holdout_loss = float(np.sort(trg_val)[:m.num_elites].mean())
+            self.history.append(dict(epoch=epoch, src=src_stats, trg=trg_stats, src_holdout=src_holdout_loss,
+                                     trg_holdout=trg_holdout_loss, src_val=src_val, trg_val=trg_val, trg_reward_val=trg_enc))
+            if writer is not None:                                                          # :890-894, 921-924
+                writer.add_scalar("src_loss/dynamics_train_loss", src_stats[1], global_step=epoch)
+                writer.add_scalar("src_loss/dynamics_encoder_loss", src_stats[2], global_step=epoch)
+                writer.add_scalar("src_loss/dynamics_domain_loss", src_stats[3], global_step=epoch)
+                writer.add_scalar("src_loss/dynamics_holdout_loss", src_holdout_loss, global_step=epoch)
+                writer.add_scalar("trg_loss/dynamics_train_loss", trg_stats[1], global_step=epoch)
+                writer.add_scalar("trg_loss/dynamics_encoder_loss", trg_stats[2], global_step=epoch)
+                writer.add_scalar("trg_loss/dynamics_holdout_loss", trg_holdout_loss, global_step=epoch)
+            src_idx = bc(self.shuffle_rows(src_idx).contiguous())                           # :934-935
+            trg_idx = bc(self.shuffle_rows(trg_idx).contiguous())
+            indexes = []
+            for i, new_loss, old_loss in zip(range(E), trg_val, trg_holdout_losses):        # :937-942
+                if (old_loss - new_loss) / old_loss > 0.01:
+                    indexes.append(i)
+                    trg_holdout_losses[i] = new_loss
+            if len(indexes) > 0:
+                m.update_save(indexes)
+                cnt = 0
+            else:
+                cnt += 1
+            if (cnt >= max_epochs_since_update) or (max_epochs and (epoch >= max_epochs)):  # :951
+                break
+        indexes = self.select_elites(trg_holdout_losses)
+        m.set_elites(indexes)
+        m.load_save()
+        m.training = False
+        self.trg_holdout_losses = trg_holdout_losses
+        print("elites:{} , holdout loss: {}".format(indexes, (np.sort(trg_holdout_losses)[:m.num_elites]).mean()))
 
     def save(self, save_path):
         torch.save(self.model.state_dict(), os.path.join(save_path, "dynamics.pth"))        # :1158-1161

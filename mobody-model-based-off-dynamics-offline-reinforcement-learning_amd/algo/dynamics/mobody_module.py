@@ -5,8 +5,11 @@ Keeps the reference constructor signature (:50-64), the parameter names/shapes o
 `max/min_logvar(_latent)`, `elites`), the elite bookkeeping (`set_elites` :351-353,
 `random_elite_idxs` :355-357) and `inference()/uninference()`.  The forward passes run in the HIP
 library on a packed copy of the weights (`packed()`, refreshed whenever the tensors change).
-Training-time pieces (reparameterisation noise, decoders, weight decay) belong to the dynamics
-pre-training row of SURVEY 8(f) and are not part of this path.
+Pre-training (`MOBODYEnsembleDynamics.train/learn`) works on a second packed copy, the TRAINING blob
+(`train_state()`: csrc/pretrain.hip's MobodyPretrainLayout with its transposes, gradient and Adam moments);
+while it is ahead of the reference-layout tensors `_p` it is the master, and every reader of `_p`
+(`state_dict`, `packed`, `update_save`) first pulls it back (`_sync_from_train`).  The action decoders
+`za_de_*` take no part in any loss (their .grad is None in the reference) and are only carried in the state_dict.
 """
 import numpy as np
 import torch
@@ -52,6 +55,8 @@ class MOBODYModule(object):
         self._p["min_logvar_latent"] = torch.ones(LATENT, device=self.device) * -20
         self._p["elites"] = torch.arange(self.num_elites, device=self.device)
         self._blob = None
+        self._train, self._train_ahead = None, False
+        self.layer_names = list(dims)                              # module_list order, mobody_module.py:97-150
 
     # ---- nn.Module-like surface ----
     @property
@@ -59,9 +64,12 @@ class MOBODYModule(object):
         return self._p["elites"]
 
     def state_dict(self):
+        self._sync_from_train()
         return {k: v.detach().clone() for k, v in self._p.items()}
 
     def load_state_dict(self, sd, strict=True):
+        self._sync_from_train()
+        self._train = None                                          # Adam moments belong to the old weights
         for k, v in sd.items():
             if k not in self._p:
                 if strict:
@@ -82,6 +90,8 @@ class MOBODYModule(object):
 
     def broadcast_(self, dist, src=0):
         """Data parallel: adopt rank `src`'s tensors (every rank rolls out with the same model)."""
+        self._sync_from_train()
+        self._train = None
         for k in sorted(self._p):
             dist.broadcast(self._p[k], src)
         self._blob = None
@@ -96,6 +106,7 @@ class MOBODYModule(object):
         self.training = True
 
     def set_elites(self, indexes):
+        indexes = [int(i) for i in indexes]
         assert len(indexes) <= self.num_ensemble and max(indexes) < self.num_ensemble
         self._p["elites"] = torch.as_tensor(list(indexes), dtype=torch.int64, device=self.device)
 
@@ -103,15 +114,56 @@ class MOBODYModule(object):
         return np.random.choice(self.elites.cpu().numpy(), size=batch_size)      # NumPy global RNG, :355-357
 
     def load_save(self):
+        """EnsembleLinear.load_save for every layer (mobody_module.py:337-339,407-409): weight <- saved_weight."""
+        self._sync_from_train()
         for k in list(self._p):
             if k.endswith(".saved_weight"):
                 self._p[k[:-13] + ".weight"] = self._p[k].clone()
             if k.endswith(".saved_bias"):
                 self._p[k[:-11] + ".bias"] = self._p[k].clone()
         self._blob = None
+        self._push_to_train()
+
+    def update_save(self, indexes):
+        """EnsembleLinear.update_save for every layer (:341-343,411-413): saved[idx] <- weight[idx] for the members that
+        improved on the holdout set."""
+        self._sync_from_train()
+        idx = torch.as_tensor(list(indexes), dtype=torch.long, device=self.device)
+        for name in self.layer_names:
+            self._p[name + ".saved_weight"][idx] = self._p[name + ".weight"][idx]
+            self._p[name + ".saved_bias"][idx] = self._p[name + ".bias"][idx]
+
+    # ---- training blob (dynamics pre-training) ----
+    def train_state(self):
+        """dict(blob, blob_T, grad, m, v, t_main, t_za={False: .., True: ..}) of the packed training copy."""
+        if self._train is None:
+            blob = packing.pack_pretrain(self._p, self.obs_dim, self.action_dim, self.device)
+            z = lambda: torch.zeros_like(blob)
+            self._train = dict(blob=blob, blob_T=ops.pretrain_transpose(blob, self.obs_dim, self.action_dim), grad=z(),
+                               m=z(), v=z(), t_main=0, t_za={False: 0, True: 0})
+        return self._train
+
+    def mark_trained(self):
+        """The training blob moved (an optimizer step ran): `_p` and the inference blob are stale until pulled."""
+        self._train_ahead = True
+        self._blob = None
+
+    def _sync_from_train(self):
+        if self._train is not None and self._train_ahead:
+            packing.unpack_pretrain(self._train["blob"], self.obs_dim, self.action_dim, into=self._p)
+            self._train_ahead = False
+            self._blob = None
+
+    def _push_to_train(self):
+        """`_p` changed under a live training blob (load_save): re-pack the weights, keep the Adam state."""
+        if self._train is not None:
+            self._train["blob"].copy_(packing.pack_pretrain(self._p, self.obs_dim, self.action_dim, self.device))
+            ops.pretrain_transpose(self._train["blob"], self.obs_dim, self.action_dim, out=self._train["blob_T"])
+            self._train_ahead = False
 
     # ---- HIP side ----
     def packed(self):
+        self._sync_from_train()
         if self._blob is None:
             self._blob = packing.pack_dynamics(self._p, self.obs_dim, self.action_dim, self.device)
         return self._blob

@@ -8,8 +8,9 @@ dynamics -> attach -> `policy.train(...)` loop (:927-928).
 Simulators (gym / mujoco-py / d4rl) and datasets are not part of this build: `--synthetic 1` (the
 default when gym/d4rl are not importable) fills the replay buffers with synthetic MuJoCo-shaped
 transitions and random-initialised networks and skips simulator evaluation; with
-`--synthetic 0` the script needs d4rl/gym exactly like the reference and a `--dynamics_path` with a
-pretrained `dynamics.pth` (dynamics pre-training is a 'next' row).
+`--synthetic 0` the script needs d4rl/gym exactly like the reference.  `--train_dynamics 1` pre-trains the
+ensemble dynamics on the buffers (MOBODYEnsembleDynamics.train) and saves it under `--dynamics_path` in the
+reference's directory scheme; an existing `dynamics.pth` there is loaded instead when `--train_dynamics 0`.
 """
 import argparse
 import json
@@ -63,6 +64,7 @@ def build_parser():
     p.add_argument("--src_rows", default=int(1e6), type=int)
     p.add_argument("--tar_rows", default=5000, type=int)
     p.add_argument("--log_every", default=1000, type=int)
+    p.add_argument("--dynamics_max_epochs", default=None, type=int, help="cap on pre-training epochs (reference: until early stopping)")
     return p
 
 
@@ -178,11 +180,21 @@ def main(argv=None):
         save_dir = os.path.join(args.dynamics_path, args.env,
                                 f"srcdatatype-{args.srctype}-tardatatype-{args.tartype}-{args.shift_level}")
     if save_dir is not None and os.path.exists(os.path.join(save_dir, "dynamics.pth")) and args.train_dynamics == 0:
-        dynamics.load(save_dir)
+        dynamics.load(save_dir)                                            # train_mobody.py:821-827, 848-851
         print("----------pretrained dynamics loaded----------")
+    elif args.train_dynamics == 1:
+        # pre-train on the buffers exactly as the reference does when nothing can be loaded (:817-877):
+        # dynamics.train(src_buffer.sample_all(False), tar_buffer.sample_all(False)), then save under dynamics_path
+        synthetic.alive_dynamics(model, task)
+        dynamics.optim = type("Opt", (), {"param_groups": [{"lr": args.dynamics_lr}]})()
+        dynamics.train(src_rb.sample_all(), tar_rb.sample_all(), writer=None, buffer=[src_rb, tar_rb],
+                       max_epochs=args.dynamics_max_epochs)
+        if save_dir is not None:
+            os.makedirs(save_dir, exist_ok=True)
+            dynamics.save(save_dir)
     else:
         synthetic.alive_dynamics(model, task)
-        print("synthetic mode: random-initialised ensemble dynamics (no pre-training on this path)")
+        print("synthetic mode: random-initialised ensemble dynamics (pass --train_dynamics 1 to pre-train it on the buffers)")
     config.update({"dynamics": dynamics})
     policy.dynamics = dynamics
 

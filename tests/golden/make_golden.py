@@ -626,7 +626,36 @@ def g12():
         save(f"g12_pretrain_{tag}", **out)
 
 
+def g13():
+    """MOBODYEnsembleDynamics.train (mobody_dynamics.py:731-978) end to end on a tiny data set, max_epochs=2: holdout
+    split (random_split), bootstrap indices (torch.randint), per-epoch learn(src) + 3 x learn(trg), validate, per-member
+    early-stopping bookkeeping (update_save on > 1 % improvement), shuffle_rows, select_elites / set_elites / load_save."""
+    S, A, bs = 17, 6, 32
+    dyn, m, p = make_dyn_trainer(S, A, 221)
+    src = gi.batch(901, 150, S, A); trg = gi.batch(902, 90, S, A)
+    rec = []
+    o_val = dyn.validate
+
+    def validate(*a, **k):
+        r = o_val(*a, **k); rec.append(np.array([r[0], r[1]], np.float64)); return r
+
+    dyn.validate = validate
+    torch.manual_seed(41); np.random.seed(41)
+    with NoiseTap(1300) as tap, CudaAlias():
+        dyn.train(tuple(torch.from_numpy(x) for x in src), tuple(torch.from_numpy(x) for x in trg), max_epochs=2, batch_size=bs)
+    sd = m.state_dict()
+    out = dict(S=S, A=A, bs=bs, seed=221, alive_val=0.85, wsum=gi.checksum(p), noise_seed=1300, rng_seed=41, lr=1e-3,
+               n_src=150, n_trg=90, validate=np.stack(rec), elites=sd["elites"].numpy(), n_noise=len(tap.shapes),
+               total_steps=dyn.total_steps)
+    for k, v in sd.items():
+        if k.split(".")[0] in [n for n, _, _ in gi.dyn_layer_dims(S, A)]:
+            out["sd::" + k] = sub101(v.numpy())
+    print("train: elites", out["elites"], "validate calls", len(rec), "noise calls", len(tap.shapes), "steps", dyn.total_steps)
+    print(np.stack(rec)[:, 0])
+    save("g13_dyn_train", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()

@@ -12,7 +12,7 @@ def test_cli_flags_match_the_reference_table():
     from mobody_amd import train_mobody as tm
     want = {f["flag"]: f for f in json.load(open(os.path.join(ROOT, "tests", "golden", "g10_cli_flags.json")))}
     got = {a.option_strings[0]: a for a in tm.build_parser()._actions if a.option_strings and a.option_strings[0] != "-h"}
-    extra = {"--synthetic", "--rng", "--src_rows", "--tar_rows", "--log_every"}            # additions of this build
+    extra = {"--synthetic", "--rng", "--src_rows", "--tar_rows", "--log_every", "--dynamics_max_epochs"}            # additions of this build
     assert set(got) - extra == set(want)
     for flag, f in want.items():
         a = got[flag]
@@ -56,3 +56,28 @@ def test_cli_runs_end_to_end_on_synthetic_buffers(tmp_path, capsys):
     assert sorted(os.listdir(models)) == ["model_actor", "model_actor_optimizer", "model_critic", "model_critic_optimizer"]
     sd = torch.load(os.path.join(models, "model_actor"), weights_only=True)
     assert sorted(sd) == sorted(f"network.network.{i}.{w}" for i in (0, 2, 4) for w in ("weight", "bias"))
+
+
+@pytest.mark.gpu
+def test_cli_pretrains_saves_and_reloads_the_dynamics(tmp_path, capsys):
+    """--train_dynamics 1: MOBODYEnsembleDynamics.train on the buffers, saved in the reference's directory scheme
+    (train_mobody.py:817-877); a second run with --train_dynamics 0 finds and loads it (:848-851)."""
+    import torch
+    from mobody_amd import train_mobody as tm
+    common = ["--policy", "MOBODY", "--env", "walker2d_friction", "--shift_level", "2.0", "--mode", "3", "--seed", "2",
+              "--synthetic", "1", "--rng", "device", "--penalty_type", "none", "--src_rows", "3000", "--tar_rows", "900",
+              "--params", '{"batch_size": 128, "max_step": 3}', "--max_step", "3", "--dir", str(tmp_path),
+              "--dynamics_path", str(tmp_path / "dyn")]
+    os.makedirs(tmp_path / "dyn" / "walker2d-friction", exist_ok=True)
+    pol = tm.main(common + ["--train_dynamics", "1", "--dynamics_max_epochs", "2"])
+    d = pol.dynamics
+    assert d.total_steps == 2 * (10 + 3 * 3) and len(d.history) == 2           # 2400 / 256 = 10 source, 720 / 256 = 3 target batches
+    assert d.history[1]["trg_holdout"] < d.history[0]["trg_holdout"]           # it learns
+    save = tmp_path / "dyn" / "walker2d-friction" / "srcdatatype-medium-tardatatype-medium-2.0"
+    assert sorted(os.listdir(save)) == ["dynamics.pth", "mu.npy", "std.npy"]
+    sd = torch.load(save / "dynamics.pth", weights_only=True)
+    assert "zs1.saved_weight" in sd and "za_de_trg2.bias" in sd and sd["elites"].shape == (5,)
+    pol2 = tm.main(common + ["--train_dynamics", "0"])
+    assert "pretrained dynamics loaded" in capsys.readouterr().out
+    sd2 = pol2.dynamics.model.state_dict()
+    assert all(torch.equal(sd[k].to(sd2[k].device), sd2[k]) for k in sd)

@@ -197,3 +197,99 @@ def test_dyn_validate_vs_oracle(dev):
             rl = ((pr - O.T(r)) ** 2).mean(dim=(1, 2))
         close(out[:7], tl, rtol=1e-5, atol=1e-7)
         close(out[7:], rl, rtol=1e-5, atol=1e-7)
+
+
+def _mirror_dynamics(p, S, A, dev, cfg_over=None):
+    from mobody_amd.algo.dynamics.mobody_module import MOBODYModule
+    from mobody_amd.algo.dynamics.mobody_dynamics import MOBODYEnsembleDynamics
+    from mobody_amd.algo.mb_utils.terminal_funs import get_termination_fn
+    cfg = gu.policy_cfg(S, A, no_vae=0, inverse_sep_reward_loss=0, train_together=0, train_with_src_threshold=1,
+                        dynamics_lr=1e-3, **(cfg_over or {}))
+    m = MOBODYModule(S, A, 256, 7, 5, device=dev, config=cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()}, strict=False)
+    return MOBODYEnsembleDynamics(cfg, m, None, None, get_termination_fn("walker2d-medium-v2"), penalty_coef=0.1), m
+
+
+def test_mirror_dynamics_train_vs_reference_golden(dev):
+    """MOBODYEnsembleDynamics.train end to end (fixture g13: the reference's own train() on 150 + 90 rows, max_epochs=2,
+    batch 32): same holdout split / bootstrap / shuffle index streams (torch CPU generator + NumPy seeded as in the
+    golden run), the reference's noise stream, 26 optimizer steps, 4 validate() calls, early-stopping bookkeeping,
+    elites, load_save.  Validation losses 1e-4 relative after up to 26 chained steps (per-step parity is pinned at 1e-5
+    by test_pretrain_steps_vs_reference_golden); final weights 5e-4 absolute (= 0.5 lr)."""
+    g = gu.load("g13_dyn_train")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    p = gu.dyn_params_for(g)
+    dyn, m = _mirror_dynamics(p, S, A, dev)
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    td = lambda x: torch.from_numpy(x).to(dev)
+
+    def noise(b):
+        nz = noise7(rng, b, S)
+        return td(np.stack(nz[:6])), td(nz[6])
+
+    dyn.train_noise_fn = noise
+    src = gu.gi.batch(901, int(g["n_src"]), S, A); trg = gu.gi.batch(902, int(g["n_trg"]), S, A)
+    torch.manual_seed(int(g["rng_seed"])); np.random.seed(int(g["rng_seed"]))
+    dyn.train(tuple(torch.from_numpy(x) for x in src), tuple(torch.from_numpy(x) for x in trg), max_epochs=2, batch_size=bs)
+    assert dyn.total_steps == int(g["total_steps"]) and dyn._train_calls == int(g["n_noise"]) // 7
+    want = g["validate"]                                   # [4 calls][transition | reward][7]
+    got = []
+    for h in dyn.history:
+        got += [h["src_val"], h["trg_val"]]
+    close(np.array(got), want[:, 0], rtol=1e-4, atol=1e-8)
+    close(np.array(dyn.history[-1]["trg_reward_val"]), want[-1, 1], rtol=1e-4, atol=1e-8)
+    # elites: same members; order may only differ between members whose holdout losses are within 1e-4 of each other
+    el, wel = [int(x) for x in m.elites.tolist()], [int(x) for x in g["elites"]]
+    assert sorted(el) == sorted(wel)
+    fin = want[-1, 0]
+    for a_, b_ in zip(el, wel):
+        assert a_ == b_ or abs(fin[a_] - fin[b_]) <= 1e-4 * abs(fin[b_]), (el, wel)
+    sd = m.state_dict()
+    for k in g:
+        if k.startswith("sd::"):
+            d = np.abs(gu.sub101(sd[k[4:]].cpu().numpy()).astype(np.float64) - g[k])
+            assert d.max() <= 5e-4, (k, d.max())
+            assert (d <= 1e-5 + 1e-4 * np.abs(g[k])).mean() >= 0.98, (k, (d <= 1e-5 + 1e-4 * np.abs(g[k])).mean())
+    # weight == saved_weight after load_save, and the inference path runs on the trained model
+    assert torch.equal(sd["zs1.weight"], sd["zs1.saved_weight"])
+    r = dyn.step_device(td(src[0][:8]), td(src[1][:8]))
+    assert torch.isfinite(r["next_obs"]).all()
+
+
+def test_mirror_learn_public_signature(dev):
+    """learn(use_trg, obss[7,n,S], actions, next_obss, rewards, batch_size, logvar_loss_coef) -- the reference's own
+    call shape (:594) -- equals the C-ABI driver fed with the same rows and noise."""
+    S, A, b = 17, 6, 24
+    p = gu.gi.dyn_params(5, S, A)
+    dyn, m = _mirror_dynamics(p, S, A, dev)
+    rows = gu.gi.pretrain_batch(5, 2 * b + 7, S, A)
+    rng1, rng2 = np.random.default_rng(3), np.random.default_rng(3)
+    td = lambda x: torch.from_numpy(x).to(dev)
+
+    def noise(bb):
+        nz = noise7(rng1, bb, S)
+        return td(np.stack(nz[:6])), td(nz[6])
+
+    dyn.train_noise_fn = noise
+    stats = dyn.learn(True, *[torch.from_numpy(x) for x in rows], b, 0.01)
+    tr = Trainer(p, S, A, b, dev)
+    ls = []
+    for k in range(3):
+        sl = slice(k * b, min((k + 1) * b, 2 * b + 7))
+        bb = sl.stop - sl.start
+        if bb != tr.b:
+            tr = _retarget(tr, bb)
+        ls.append(tr.grads(tuple(x[:, sl] for x in rows), noise7(rng2, bb, S), True))
+        tr.apply(True)
+    close(np.array(stats), np.mean(ls, 0), rtol=1e-5, atol=1e-6)
+    got = m.state_dict()
+    full2 = {k: torch.from_numpy(p[k]).to(dev) for k in ("za_src2.weight", "za_trg2.weight", "za_src2.bias", "za_trg2.bias")}
+    for k, v in tr.unpack(tr.blob, full2).items():
+        assert torch.equal(got[k], v), k
+
+
+def _retarget(tr, b):
+    """Same training state, workspace for another batch size."""
+    tr.b = b
+    tr.ws = tr.ops.pretrain_workspace(tr.S, tr.A, b, tr.dev)
+    return tr
