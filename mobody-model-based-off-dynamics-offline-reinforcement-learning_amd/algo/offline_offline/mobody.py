@@ -115,7 +115,8 @@ class _Adam(object):
         if self.t == 0:
             state = {}
         group = dict(lr=self.lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, maximize=False,
-                     foreach=None, capturable=False, differentiable=False, fused=None, params=list(range(len(ms))))
+                     foreach=None, capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False,
+                     params=list(range(len(ms))))
         return dict(state=state, param_groups=[group])
 
     def load_state_dict(self, sd):

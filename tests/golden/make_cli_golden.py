@@ -27,3 +27,25 @@ for node in ast.walk(ast.parse(open(REF).read())):
                           action=lit(kw["action"]) if "action" in kw else None))
 json.dump(sorted(flags, key=lambda f: f["flag"]), open(OUT, "w"), indent=1)
 print(len(flags), "flags ->", OUT)
+
+
+# ---- the merged config dict (train_mobody.py:470-531): every key of the `config.update({...})` literal and the
+# expression it is bound to, as data; plus the yaml files of the MOBODY configs the reference ships (parsed values)
+import glob
+
+import yaml
+
+OUT2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "g10b_config_merge.json")
+tree = ast.parse(open(REF).read())
+merge = None
+for node in ast.walk(tree):
+    if (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "update"
+            and isinstance(node.func.value, ast.Name) and node.func.value.id == "config" and node.args
+            and isinstance(node.args[0], ast.Dict) and len(node.args[0].keys) > 20):
+        merge = [(ast.literal_eval(k), ast.unparse(v)) for k, v in zip(node.args[0].keys, node.args[0].values)]
+assert merge is not None
+yamls = {}
+for f in sorted(glob.glob("/root/reference/config/*/mobody/*.yaml")):
+    yamls["/".join(f.split("/")[-3:])] = yaml.safe_load(open(f, encoding="utf-8"))
+json.dump(dict(update=merge, yaml=yamls), open(OUT2, "w"), indent=1)
+print(len(merge), "config keys,", len(yamls), "yaml files ->", OUT2)

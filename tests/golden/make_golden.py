@@ -655,7 +655,98 @@ def g13():
     save("g13_dyn_train", **out)
 
 
+def g14():
+    """Target-data ingestion, dataset/call_dataset.py:21-109 (`call_tar_dataset`): the HDF5 arrays -> transitions
+    transformation.  The module imports gym, d4rl and h5py, none of which exist in this image; the harness pre-seeds
+    sys.modules with minimal stand-ins (gym.make -> an object with _max_episode_steps, h5py.File -> an in-memory
+    group over the fixture arrays) so that the reference's own loop runs on known arrays.  Inputs and the function's
+    outputs are stored; nothing of the reference's text is."""
+    class DS:
+        def __init__(self, a): self.a = a
+        def __getitem__(self, k): return self.a[k]
+
+    cur = {}
+
+    class File:
+        def __init__(self, path, mode): self.path = path
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def visititems(self, fn):
+            for k, v in cur.items():
+                fn(k, DS(v))
+        def __getitem__(self, k): return DS(cur[k])
+
+    h5 = types.ModuleType("h5py"); h5.File = File; h5.Dataset = DS
+    gymm = types.ModuleType("gym"); gymm.make = lambda name: types.SimpleNamespace(_max_episode_steps=10)
+    for name, mod in (("h5py", h5), ("gym", gymm), ("d4rl", types.ModuleType("d4rl"))):
+        sys.modules.setdefault(name, mod)
+    from dataset.call_dataset import call_tar_dataset
+    rng = np.random.default_rng(14)
+    out = {}
+    for tag, with_timeouts, rew2d in (("a", True, False), ("b", False, True)):
+        N, S, A = 57, 17, 6
+        cur.clear()
+        cur.update(observations=rng.standard_normal((N, S)).astype(np.float64), actions=rng.uniform(-1, 1, (N, A)).astype(np.float32),
+                   rewards=rng.standard_normal((N, 1) if rew2d else N).astype(np.float64),
+                   terminals=(rng.uniform(size=N) > 0.9))
+        if with_timeouts:
+            cur["timeouts"] = (np.arange(N) % 10 == 9)
+        res = call_tar_dataset("walker2d-friction", 2.0, "medium")
+        for k, v in cur.items():
+            out[f"{tag}_in_{k}"] = v.copy()
+        for k, v in res.items():
+            out[f"{tag}_out_{k}"] = np.asarray(v)
+        print("ingest", tag, {k: (np.asarray(v).shape, np.asarray(v).dtype) for k, v in res.items()})
+    save("g14_ingest", **out)
+
+
+def g16():
+    """Policy checkpoints written by the REFERENCE's own MOBODY.save (mobody.py:584-588) after two train() steps of the
+    G7 default setup -> tests/golden/ckpt_ref/model_{actor,critic,actor_optimizer,critic_optimizer} (plain tensors,
+    loadable with weights_only=True), plus what the reference computes in step 3 when it continues from them."""
+    S, A, bs = 17, 6, 32
+    cfg = policy_cfg(S, A)
+    pol, pa, pq, pv = make_policy(cfg, 401)
+    src = FixedRB(gi.batch(501, 64, S, A)); tar = FixedRB(gi.batch(502, 64, S, A)); fake = FixedRB(gi.batch(503, 64, S, A))
+    pol.fake_replay_buffer = fake
+    rec = dict(q_loss=[], pi_loss=[], bc_loss=[])
+    for nm, key in (("update_q_functions", "q_loss"), ("update_policy", "pi_loss"), ("bc_loss", "bc_loss")):
+        def mk(orig, key):
+            def f(*a, **k):
+                o = orig(*a, **k); rec[key].append(float(o.detach())); return o
+            return f
+        setattr(pol, nm, mk(getattr(pol, nm), key))
+    pol.total_it = 1
+    dummy = types.SimpleNamespace(log=lambda *a, **k: None)
+    for _ in range(2):
+        pol.train(src, tar, bs, None, dummy)
+    d = os.path.join(HERE, "ckpt_ref")
+    os.makedirs(d, exist_ok=True)
+    pol.save(os.path.join(d, "model"))
+    # continue the way a user of the reference would: a FRESH policy object (same initial weights, so its target
+    # critic is the initial critic -- MOBODY.load does not restore target_q_funcs, :589-594) loads the files, then trains
+    rec = dict(q_loss=[], pi_loss=[], bc_loss=[])
+    pol, _, _, _ = make_policy(cfg, 401)
+    pol.fake_replay_buffer = fake
+    for nm, key in (("update_q_functions", "q_loss"), ("update_policy", "pi_loss"), ("bc_loss", "bc_loss")):
+        def mk2(orig, key):
+            def f(*a, **k):
+                o = orig(*a, **k); rec[key].append(float(o.detach())); return o
+            return f
+        setattr(pol, nm, mk2(getattr(pol, nm), key))
+    pol.load(os.path.join(d, "model"))
+    pol.total_it = 3
+    pol.train(src, tar, bs, None, dummy)
+    out = dict(S=S, A=A, bs=bs, seed=401, q_loss=np.array(rec["q_loss"]), pi_loss=np.array(rec["pi_loss"]),
+               bc_loss=np.array(rec["bc_loss"]))
+    for nm, mod in (("q", pol.q_funcs), ("actor", pol.policy)):
+        for k, v in mod.state_dict().items():
+            out[f"s3_{nm}_p::{k}"] = sub(v.numpy())
+    print("ckpt files", {f: os.path.getsize(os.path.join(d, f)) for f in sorted(os.listdir(d))}, "losses", rec["q_loss"])
+    save("g16_ckpt_step3", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g16"]
     for w in which:
         globals()[w]()

@@ -81,3 +81,30 @@ def test_cli_pretrains_saves_and_reloads_the_dynamics(tmp_path, capsys):
     assert "pretrained dynamics loaded" in capsys.readouterr().out
     sd2 = pol2.dynamics.model.state_dict()
     assert all(torch.equal(sd[k].to(sd2[k].device), sd2[k]) for k in sd)
+
+
+def test_merged_config_matches_the_reference_mapping():
+    """C1 pin: the reference's `config.update({...})` literal (train_mobody.py:470-531) as data -- every
+    key and the expression it is bound to (fixture g10b, extracted with ast) -- evaluated on the parsed args must equal
+    what build_config produces, key for key; the yaml layer equals the reference's shipped yaml files."""
+    from mobody_amd import train_mobody as tm
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "g10b_config_merge.json")))
+    argv = ["--policy", "MOBODY", "--env", "walker2d-friction", "--shift_level", "2.0", "--bc_coef", "0.25", "--scale_q", "0",
+            "--rollout_from_src", "1", "--env_filter", "3.5", "--trg_ratio", "0.5", "--penalty_type", "dara",
+            "--src_rollout_length", "4", "--params", '{"batch_size": 64}']
+    args = tm.build_parser().parse_args(argv)
+    cfg = tm.build_config(args, 17, 6, 1.0)
+    scope = dict(args=args, state_dim=17, action_dim=6, max_action=1.0, shift_level=2.0, int=int)
+    want = {k: eval(expr, {"__builtins__": {}}, scope) for k, expr in g["update"]}      # plain attribute / int() expressions
+    for k, v in want.items():
+        assert cfg[k] == v and type(cfg[k]) is type(v), (k, cfg[k], v)
+    y = g["yaml"]["mujoco/mobody/walker2d.yaml"]
+    extra = set(cfg) - set(want) - set(y)
+    assert extra == {"rng", "seed"}, extra                     # this build's two additions, nothing else
+    for k, v in y.items():
+        if k not in want and k != "batch_size":
+            assert cfg[k] == v, (k, cfg[k], v)
+    assert cfg["batch_size"] == 64
+    for name in ("ant", "halfcheetah", "hopper"):             # the built-in yaml copy covers all four shipped files
+        yy = g["yaml"][f"mujoco/mobody/{name}.yaml"]
+        assert {k: v for k, v in yy.items() if k != "eval_freq"} == {k: v for k, v in y.items() if k != "eval_freq"}

@@ -541,3 +541,45 @@ def test_dara_penalize_fake_vs_reference_golden(dev):
             close(gu.sub(v.cpu().numpy()), g["cls_g::" + net.prefixes[0] + k], rtol=1e-5, atol=1e-5 * scale)
     for k, v in pol.classifier.state_dict().items():
         params_close(gu.sub(v.cpu().numpy()), g["cls_p::" + k], cfg["actor_lr"], max_frac=0.5)
+
+
+def test_reference_written_checkpoint_loads_and_continues(dev):
+    """tests/golden/ckpt_ref/model_* were written by the REFERENCE's MOBODY.save after two train() steps (make_golden.g16).
+    The mirror loads them (weights_only=True), exposes the same tensors, and its next train() step equals the step the
+    reference takes from the same files (fixture g16: losses, post-step parameters) -- which pins the optimizer state
+    mapping (exp_avg, exp_avg_sq, step) as well as the weights."""
+    from mobody_amd.algo.offline_offline.mobody import MOBODY
+    from test_hip_train import params_close
+    g = gu.load("g16_ckpt_step3")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    cfg = gu.policy_cfg(S, A)
+    pol = MOBODY(cfg, dev)
+    pa, pq, _ = gu.policy_params(int(g["seed"]), S, A)
+    pol.policy.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
+    pol.q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+    pol.target_q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+    prefix = os.path.join(gu.GOLDEN, "ckpt_ref", "model")
+    pol.load(prefix)
+    ref = {s: torch.load(prefix + s, map_location="cpu", weights_only=True) for s in ("_actor", "_critic", "_actor_optimizer", "_critic_optimizer")}
+    for k, v in pol.policy.state_dict().items():
+        assert torch.equal(v.cpu(), ref["_actor"][k]), k
+    for k, v in pol.q_funcs.state_dict().items():
+        assert torch.equal(v.cpu(), ref["_critic"][k]), k
+    for opt, name in ((pol.policy_optimizer, "_actor_optimizer"), (pol.q_optimizer, "_critic_optimizer")):
+        sd = opt.state_dict()
+        assert opt.t == 2 and set(sd["param_groups"][0]) == set(ref[name]["param_groups"][0])
+        for i, st in ref[name]["state"].items():
+            assert torch.equal(sd["state"][i]["exp_avg"].cpu(), st["exp_avg"]) and float(sd["state"][i]["step"]) == 2.0
+            assert torch.equal(sd["state"][i]["exp_avg_sq"].cpu(), st["exp_avg_sq"])
+    src = FixedRows(gu.gi.batch(501, 64, S, A), S, A, dev).rb
+    tar = FixedRows(gu.gi.batch(502, 64, S, A), S, A, dev).rb
+    pol.fake_replay_buffer = FixedRows(gu.gi.batch(503, 64, S, A), S, A, dev).rb
+    pol.total_it = 3
+    pol.train(src, tar, bs, None, None)
+    q_loss, pi_loss, bc_loss = pol.losses()
+    close(q_loss, g["q_loss"][0], rtol=1e-5, atol=0)
+    close(pi_loss, g["pi_loss"][0], rtol=5e-5, atol=2e-5)
+    close(bc_loss, g["bc_loss"][0], rtol=5e-5, atol=2e-5)
+    for nm, net in (("q", pol.q_funcs), ("actor", pol.policy)):
+        for k, v in net.state_dict().items():
+            params_close(gu.sub(v.cpu().numpy()), g[f"s3_{nm}_p::{k}"], cfg["critic_lr"])
