@@ -1,73 +1,129 @@
 #!/usr/bin/env python
 """MOBODY hot-path benchmark (contract: one JSON line on rank 0).
 
-Workload (BASELINE.json configs[1]): walker2d-friction shapes S=17, A=6, ensemble 7, rollout_len 1,
-batch_size 4096 per GPU -> every `MOBODY.train()` step consumes N = 2.5*4096 = 10 240 synthetic
+Workload (default `--config c2` = BASELINE.json configs[1]): walker2d-friction shapes S=17, A=6, ensemble 7,
+rollout_len 1, batch_size 4096 per GPU -> every `MOBODY.train()` step consumes N = 2.5*4096 = 10 240 synthetic
 transitions (4096 source + 4096 target + 2048 model-generated rows) already resident in HBM:
 replay gather -> twin-Q TD update (+Adam, Polyak) -> Q-scaled actor + Q-weighted-BC update (+Adam).
-The model-rollout refresh (50 000 + 2 000 + 50 000 imagined transitions every 5000 steps,
-mobody.py:441-475) runs in the warm-up (step 1) and is measured separately below.
+The model-rollout refresh of the reference (50 000 + 2 000 init states x rollout_len + 50 000 relabels every 5000
+steps, mobody.py:441-475) is inside the timed region at the reference's cadence: K timed steps are followed by a
+refresh of K/5000 of that size (same code path, scaled row counts), so `ms_per_step` is the amortised cost of a step.
 
-  value  = minibatch transitions consumed per second by the timed K train() steps, summed over ranks
-           (weak scaling: every rank draws its own 4096-row minibatch; gradients and the two actor
-           statistics are all-reduced over RCCL each step)
-  extras = grad_steps_per_sec (train() calls/s), rollout_transitions_per_sec (actor + ensemble
-           step on 50 000 rows), per-kernel-family roofline, CPU baseline (oracle on host cores).
+  value  = minibatch transitions consumed per second by the K timed train() steps, summed over ranks (weak scaling:
+           every rank draws its own minibatch; gradients and the two actor statistics are all-reduced over RCCL)
+  also   = grad_steps_per_sec (train() calls/s, the north_star's target quantity), rollout_transitions_per_sec
+           (actor + fused ensemble step, rows produced per second), per-kernel-family roofline, CPU baseline.
+
+`--gpus N` without a torch.distributed launcher starts its N ranks itself (children are spawned before the parent
+touches the GPU); under `python -m torch.distributed.run` the ranks come from the environment.
+Other configs (`--config c1|c3|c4|c5`) are the shapes of BASELINE.json configs[0], [2], [3], [4].
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-S, A, BS, TASK = 17, 6, 4096, "walker2d-medium-v2"
 PEAK_F32_TFLOPS = 157.3          # MI355X dense fp32 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
 FAMILIES = ["k_mlp3_fwd", "k_mlp3_bwd", "k_wgrad", "k_dyn_fwd"]
+CONFIGS = {   # BASELINE.json configs[i] -> shapes (per GPU)
+    "c1": dict(S=17, A=6, bs=256, H=1, task="walker2d-medium-v2", penalty_type="none",
+               label="walker2d-friction shapes, batch 256 (the reference's CPU-runnable case)"),
+    "c2": dict(S=17, A=6, bs=4096, H=1, task="walker2d-medium-v2", penalty_type="none",
+               label="walker2d-friction shapes, batch 4096 per GPU"),
+    "c3": dict(S=17, A=6, bs=16384, H=5, task="halfcheetah-medium-v2", penalty_type="none",
+               label="halfcheetah-kinematic shapes, rollout_len 5, batch 16384"),
+    "c4": dict(S=111, A=8, bs=8192, H=1, task="ant-medium-v2", penalty_type="none",
+               label="ant-friction shapes, batch 65536 over 8 GPUs = 8192 per GPU"),
+    "c5": dict(S=45, A=24, bs=4096, H=1, task="pen-human-v1", penalty_type="dara",
+               label="adroit pen shapes, DARA penalty + mixed src/trg/rollout batch, batch 4096 per GPU"),
+}
 
 
-def macs():
+def macs(S, A):
     actor = S * 256 + 65536 + 256 * A
     q = (S + A) * 256 + 65536 + 256
-    dyn = 7 * (S * 256 + 65536 + 256 * 32 + (16 + A) * 32 + 32 * 32 + 16 * 256 + 65536 + 256 * S
-               + (2 * S + A) * 256 + 65536 + 512)
-    return actor, q, dyn
+    rw = 7 * ((2 * S + A) * 256 + 65536 + 512)
+    dyn = 7 * (S * 256 + 65536 + 256 * 32 + (16 + A) * 32 + 32 * 32 + 16 * 256 + 65536 + 256 * S) + rw
+    return actor, q, dyn, rw
 
 
-def train_flops(N, Nt):
+def train_flops(S, A, N, Nt):
     """Useful (executed) FLOPs of one train() step per kernel family; SURVEY 8(d) counts two more
     forwards that the reference executes but never uses (Q7), which this build skips."""
-    actor, q, _ = macs()
+    actor, q, _, _ = macs(S, A)
     fwd = N * (2 * actor + 6 * q) + Nt * 2 * q
     bwd = N * (2 * (256 + 65536) + 2 * (256 + 65536 + 256 * A) + (256 * A + 65536))
     wg = N * (2 * q + actor)
     return {"k_mlp3_fwd": 2.0 * fwd, "k_mlp3_bwd": 2.0 * bwd, "k_wgrad": 2.0 * wg}
 
 
-def build(dev, rank, bs, graph):
-    from mobody_amd import synthetic
+# ------------------------------------------------------------------------------------------------ launcher
+def spawn_ranks(args):
+    """Parent of `--gpus N` (no launcher in the environment): start N children, one per GPU, BEFORE anything here
+    touches the GPU (a process that has initialised HIP must not be replaced or forked from), wait, and pass rank 0's
+    JSON line through."""
+    port = int(os.environ.get("MASTER_PORT", 29000 + os.getpid() % 2000))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    for line in out.decode().splitlines():              # only the JSON line (gloo / RCCL may chat on stdout)
+        if line.startswith("{"):
+            print(line)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+# ------------------------------------------------------------------------------------------------ GPU side
+def build(dev, c, graph):
+    import numpy as np
+    import torch
+    from mobody_amd import engine, synthetic
     from mobody_amd.algo import utils
     from mobody_amd.algo.call_algo import call_algo
     from mobody_amd.algo.dynamics.mobody_dynamics import MOBODYEnsembleDynamics
     from mobody_amd.algo.dynamics.mobody_module import MOBODYModule
     from mobody_amd.algo.mb_utils.terminal_funs import get_termination_fn
-    import golden_util as gu
-    cfg = gu.policy_cfg(S, A, rng="device", seed=rank, penalty_type="none", batch_size=bs, graph=graph)
-    torch.manual_seed(rank); np.random.seed(rank)
+    S, A, bs, task = c["S"], c["A"], c["bs"], c["task"]
+    # the SAME seeds on every rank: the mirror folds the rank into its index / noise streams and broadcasts rank 0's
+    # replica before the first step, so a caller cannot get either wrong
+    cfg = engine.default_config(S, A, rng="device", seed=0, penalty_type=c["penalty_type"], batch_size=bs, graph=graph,
+                                src_rollout_length=c["H"], trg_rollout_length=c["H"])
+    torch.manual_seed(0); np.random.seed(0)
     pol = call_algo("mobody", cfg, 3, dev)
-    src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=1000000, rng="device", seed=100 + rank), 1000000, TASK, rank)
-    tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=5000, rng="device", seed=200 + rank), 5000, TASK, 1000 + rank)
-    model = synthetic.alive_dynamics(MOBODYModule(S, A, 256, 7, 5, device=dev, config=cfg), TASK)
-    pol.dynamics = MOBODYEnsembleDynamics(cfg, model, None, None, get_termination_fn(TASK), penalty_coef=0.1, rng="device", seed=300 + rank)
+    src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=1000000, rng="device", seed=100), 1000000, task, 0)
+    tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=5000, rng="device", seed=200), 5000, task, 1000)
+    model = synthetic.alive_dynamics(MOBODYModule(S, A, 256, 7, 5, device=dev, config=cfg), task)
+    pol.dynamics = MOBODYEnsembleDynamics(cfg, model, None, None, get_termination_fn(task), penalty_coef=0.1, rng="device", seed=300)
     return pol, src, tar, cfg
+
+
+def scaled_refresh(pol, src, tar, bs, steps):
+    """The fake-buffer refresh at the reference's cadence: `steps`/5000 of its 50 000 / 2 000 init states (and relabels),
+    through the product's own `_refresh`."""
+    from mobody_amd.algo.offline_offline import mobody as M
+    n_s, n_t = max(1, math.ceil(50000 * steps / 5000)), max(1, math.ceil(2000 * steps / 5000))
+    old = (M.REFRESH_SRC, M.REFRESH_TAR)
+    M.REFRESH_SRC, M.REFRESH_TAR = n_s, n_t
+    try:
+        pol._refresh(src, tar, bs)
+    finally:
+        M.REFRESH_SRC, M.REFRESH_TAR = old
+    H = pol.config["src_rollout_length"]
+    return n_s * H + n_t * pol.config["trg_rollout_length"] + n_s
 
 
 def prof_pass(pol, src, tar, bs, steps):
@@ -75,82 +131,163 @@ def prof_pass(pol, src, tar, bs, steps):
     Runs eagerly (event records are not part of a captured graph); the kernels are the same."""
     from mobody_amd import _lib
     lib = _lib.load()
-    pol.use_graph = 0
+    graph, pol.use_graph = pol.use_graph, 0
     _lib.check(lib.mobody_prof_begin(steps * 64), "prof_begin")
     for _ in range(steps):
         pol.train(src, tar, bs, None, None)
     ms = (C.c_double * 8)(); cnt = (C.c_int64 * 8)()
     _lib.check(lib.mobody_prof_end(ms, cnt, 8), "prof_end")
+    pol.use_graph = graph
     return {FAMILIES[i]: (ms[i] / steps, cnt[i] / steps) for i in range(3)}
 
 
-def rollout_rate(pol, src, reps=5, B=50000):
-    """Imagined transitions per second: actor forward + fused ensemble step on B rows (events on torch's stream,
-    which is the stream every kernel of the library is launched on)."""
-    from mobody_amd import _lib, ops
+def rollout_rate(pol, src, H, reps=5, B=50000):
+    """Imagined transitions per second: H steps of (actor forward + fused ensemble step + mask + ring append) on B
+    init states -- the refresh's rollout as the product runs it (events on torch's stream, which is the stream every
+    kernel of the library is launched on)."""
+    import torch
+    from mobody_amd import _lib
     lib = _lib.load()
     obs = src.state[:B].contiguous()
     for _ in range(2):
-        pol.dynamics.step_device(obs, pol.policy(obs))
+        pol._rollout_into_fake(obs, H)
     torch.cuda.synchronize()
-    _lib.check(lib.mobody_prof_begin(reps * 8), "prof_begin")
+    _lib.check(lib.mobody_prof_begin(reps * 8 * H), "prof_begin")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        pol.dynamics.step_device(obs, pol.policy(obs))
+        pol._rollout_into_fake(obs, H)
     e1.record(); torch.cuda.synchronize()
     ms = (C.c_double * 8)(); cnt = (C.c_int64 * 8)()
     _lib.check(lib.mobody_prof_end(ms, cnt, 8), "prof_end")
     total_ms = e0.elapsed_time(e1) / reps
-    return B / (total_ms * 1e-3), total_ms, ms[3] / reps
+    return B * H / (total_ms * 1e-3), total_ms, ms[3] / (reps * H)
 
 
-def cpu_baseline(cfg, bs, budget_s=20.0):
-    """The CPU oracle (PyTorch CPU ops, the reference's algorithm) on this host's cores, same shapes."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _mlp_params(rng, i, o, prefix):
+    import numpy as np
+    p = {}
+    for li, (a, b) in zip((0, 2, 4), ((i, 256), (256, 256), (256, o))):
+        bound = 1.0 / np.sqrt(a)
+        p[f"{prefix}network.{li}.weight"] = rng.uniform(-bound, bound, (b, a)).astype(np.float32)
+        p[f"{prefix}network.{li}.bias"] = rng.uniform(-bound, bound, (b,)).astype(np.float32)
+    return p
+
+
+def _dyn_params(rng, S, A):
+    import numpy as np
+    dims = dict(zs1=(S, 256), zs2=(256, 256), zs3=(256, 32), za_src1=(16 + A, 32), za_src2=(32, 32), za_trg1=(16 + A, 32),
+                za_trg2=(32, 32), transition1=(16, 256), transition2=(256, 256), transition3=(256, S),
+                reward_model1=(2 * S + A, 256), reward_model2=(256, 256), reward_model3=(256, 2))
+    p = {}
+    for k, (i, o) in dims.items():
+        p[k + ".weight"] = (np.clip(rng.standard_normal((7, i, o)), -2, 2) / (2 * np.sqrt(i))).astype(np.float32)
+        p[k + ".bias"] = np.zeros((7, 1, o), np.float32)
+    return p
+
+
+def cpu_baseline(c, cfg):
+    """The CPU oracle (PyTorch CPU ops, the reference's algorithm, pinned to the reference by tests/golden) on this host:
+    protocol of BASELINE.md section 3 -- grad-steps/s at C1 shapes (bs=256; 20 warm-up + 200 timed steps at all cores,
+    a bounded count at 1 thread), the bench config's own step, and transitions/s of `step` at B=4096 plus one 52 000-row
+    rollout; each at 1 thread (the reference's shipped setting, train_mobody.py:3-5,50-51) and at all cores of the GPU
+    box's CPU share.  About 30 s of CPU work in total."""
+    import numpy as np
+    import torch
+    from mobody_amd import engine, synthetic
     from oracle import mobody_oracle as O
-    import golden_util as gu
-    # the GPU box gives one GPU a 16-core CPU share (sched_getaffinity still lists every core of the host)
-    threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    torch.set_num_threads(threads)
-    N, Nt = int(2.5 * bs), 2 * bs
-    pa, pq, pv = gu.policy_params(1, S, A)
-    st = O.TrainState(pa, pq, pv)
-    batch = gu.gi.batch(3, N, S, A)
-    O.train_step(st, batch, Nt, cfg)                       # warm-up
-    t0 = time.time(); n = 0
-    while time.time() - t0 < budget_s * 0.6 or n < 2:
-        O.train_step(st, batch, Nt, cfg); n += 1
-    dt_train = (time.time() - t0) / n
-    p = O.to_torch(gu.gi.dyn_params(2, S, A))
+    ncores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    S, A, bs, task = c["S"], c["A"], c["bs"], c["task"]
     rng = np.random.default_rng(0)
-    B = 4096
-    obs = gu.gi.walker_like_obs(rng, B, S); act = rng.uniform(-1, 1, (B, A)).astype(np.float32)
-    eps = rng.standard_normal((7, B, S)).astype(np.float32); idx = rng.integers(0, 5, B)
-    with torch.no_grad():
-        O.dyn_step(p, obs, act, eps, idx, TASK, 0.1)
-        t1 = time.time(); m = 0
-        while time.time() - t1 < budget_s * 0.3 or m < 2:
-            O.dyn_step(p, obs, act, eps, idx, TASK, 0.1); m += 1
-    dt_step = (time.time() - t1) / m
-    return dict(value=N / dt_train, unit="transitions/s", cores=threads, kind="port",
-                sample=f"{n} oracle train steps at N={N} rows (S={S},A={A}) + {m} oracle dyn_step calls at B={B}; "
-                       f"torch CPU fp32, {threads} threads",
-                grad_steps_per_sec=1.0 / dt_train, rollout_transitions_per_sec=B / dt_step)
+
+    def batch(N, S_, A_):
+        mu = synthetic.alive_mean(task, S_)
+        return ((mu + 0.1 * rng.standard_normal((N, S_))).astype(np.float32), rng.uniform(-1, 1, (N, A_)).astype(np.float32),
+                (mu + 0.1 * rng.standard_normal((N, S_))).astype(np.float32), rng.standard_normal((N, 1)).astype(np.float32),
+                np.ones((N, 1), np.float32))
+
+    def train_rate(S_, A_, bs_, warm, steps, budget):
+        ocfg = engine.default_config(S_, A_)
+        pa = _mlp_params(rng, S_, A_, "network.")
+        pq = {**_mlp_params(rng, S_ + A_, 1, "network1."), **_mlp_params(rng, S_ + A_, 1, "network2.")}
+        st = O.TrainState(pa, pq, None)
+        b = batch(int(2.5 * bs_), S_, A_)
+        for _ in range(warm):
+            O.train_step(st, b, 2 * bs_, ocfg)
+        t0 = time.time(); n = 0
+        while n < steps and (time.time() - t0 < budget or n < 2):
+            O.train_step(st, b, 2 * bs_, ocfg); n += 1
+        return n / (time.time() - t0), n
+
+    def step_rate(S_, A_, B, calls, budget):
+        p = O.to_torch(_dyn_params(rng, S_, A_))
+        p["transition3.bias"] = p["transition3.bias"] + torch.from_numpy(synthetic.alive_mean(task, S_)).view(1, 1, -1)
+        obs, act = batch(B, S_, A_)[:2]
+        eps = rng.standard_normal((7, B, S_)).astype(np.float32); idx = rng.integers(0, 5, B)
+        with torch.no_grad():
+            O.dyn_step(p, obs, act, eps, idx, task, 0.1)
+            t0 = time.time(); n = 0
+            while n < calls and (time.time() - t0 < budget or n < 1):
+                O.dyn_step(p, obs, act, eps, idx, task, 0.1); n += 1
+        return B * n / (time.time() - t0), n
+
+    legs = {}
+    for threads in (ncores, 1):
+        torch.set_num_threads(threads)
+        tag = "all_cores" if threads == ncores and ncores > 1 else "1_thread"
+        c1_rate, c1_n = train_rate(17, 6, 256, 20 if threads > 1 else 3, 200 if threads > 1 else 60, 4.0)
+        cfg_rate, cfg_n = (c1_rate, c1_n) if (S, A, bs) == (17, 6, 256) else train_rate(S, A, bs, 1, 20, 4.0)
+        st_rate, st_n = step_rate(S, A, 4096, 10, 3.0)
+        ro_rate, _ = step_rate(S, A, 52000, 1, 0.0) if threads > 1 else (None, 0)
+        legs[tag] = dict(threads=threads, c1_grad_steps_per_sec=c1_rate, c1_steps_timed=c1_n,
+                         config_grad_steps_per_sec=cfg_rate, config_steps_timed=cfg_n,
+                         step_transitions_per_sec_B4096=st_rate, step_calls_timed=st_n,
+                         rollout_transitions_per_sec_52000=ro_rate)
+        if ncores == 1:
+            break
+    torch.set_num_threads(ncores)
+    main = legs.get("all_cores", legs["1_thread"])
+    N = int(2.5 * bs)
+    return dict(value=N * main["config_grad_steps_per_sec"], unit="transitions/s", cores=main["threads"], kind="port",
+                cpu_model=cpu_model(), host_cores_visible=os.cpu_count(),
+                sample=f"oracle (torch CPU fp32) on {main['threads']} threads: {main['config_steps_timed']} train steps at N={N} rows "
+                       f"(S={S},A={A}), {main['c1_steps_timed']} train steps at C1 (bs=256, N=640), {main['step_calls_timed']} dyn_step calls at "
+                       f"B=4096, one 52000-row step; the same legs at 1 thread (reference's shipped setting) under `legs`",
+                grad_steps_per_sec=main["config_grad_steps_per_sec"], c1_grad_steps_per_sec=main["c1_grad_steps_per_sec"],
+                rollout_transitions_per_sec=main["rollout_transitions_per_sec_52000"] or main["step_transitions_per_sec_B4096"],
+                legs=legs)
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch_size", type=int, default=BS)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch_size", type=int, default=None, help="override the config's per-GPU batch size")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="HIP-graph replay of the steady-state step: 0 never, 1 always, 2 auto (minibatches under 4096 rows); with N > 1 ranks the segments between the three all-reduces are replayed")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np  # noqa: F401
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -161,42 +298,57 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
-    bs = args.batch_size
+        world = torch.distributed.get_world_size()          # what the process group actually sees
+    c = dict(CONFIGS[args.config])
+    if args.batch_size:
+        c["bs"] = args.batch_size
+    S, A, bs = c["S"], c["A"], c["bs"]
     N, Nt = int(2.5 * bs), 2 * bs
-    pol, src, tar, cfg = build(dev, rank, bs, args.graph)
+    pol, src, tar, cfg = build(dev, c, args.graph)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):                  # step 1 includes the model-rollout refresh
+    for _ in range(max(args.warmup, 1)):                  # step 1 includes the full model-rollout refresh (and the DARA warm-up)
         pol.train(src, tar, bs, None, None)
+    scaled_refresh(pol, src, tar, bs, args.steps)         # warm the scaled refresh's shapes too
     barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     t0 = time.perf_counter()
+    ev[0].record()
     for _ in range(args.steps):
         pol.train(src, tar, bs, None, None)
+    ev[1].record()
+    rolled = scaled_refresh(pol, src, tar, bs, args.steps)
     barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t1 = time.perf_counter()
+    t = torch.tensor([t1 - t0, ev[0].elapsed_time(ev[1]) * 1e-3], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item())
+    dt, dt_steps = float(t[0]), float(t[1])
     losses = pol.losses()
+    replicas_identical = None
+    if world > 1:                                         # data-parallel replicas must still be bit-identical
+        h = torch.stack([b.double().sum() for b in (pol.q_funcs.blob, pol.target_q_funcs.blob, pol.policy.blob)])
+        hs = [torch.zeros_like(h) for _ in range(world)]
+        torch.distributed.all_gather(hs, h)
+        replicas_identical = all(torch.equal(hs[0], x) for x in hs)
 
     # the instrumented passes call train() (collectives when world > 1): every rank runs them, rank 0 reports
     fam = prof_pass(pol, src, tar, bs, 20)
-    roll_rate, roll_ms, dynfwd_ms = rollout_rate(pol, src)
+    roll_rate, roll_ms, dynfwd_ms = rollout_rate(pol, src, c["H"])
     out = None
     if rank == 0:
-        fl = train_flops(N, Nt)
+        fl = train_flops(S, A, N, Nt)
         kern = {}
         for k in ("k_mlp3_fwd", "k_mlp3_bwd", "k_wgrad"):
             ms, cnt = fam[k]
             kern[k] = dict(launches_per_step=cnt, ms_per_step=ms, tflops=fl[k] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
-        _, _, dyn = macs()
+        _, _, dyn, rw = macs(S, A)
         kern["k_dyn_fwd"] = dict(launches_per_step=1, ms_per_step=dynfwd_ms,
-                                 tflops=2.0 * (dyn - 7 * ((2 * S + A) * 256 + 65536 + 512)) * 50000 / (dynfwd_ms * 1e-3) / 1e12)
+                                 tflops=2.0 * (dyn - rw) * 50000 / (dynfwd_ms * 1e-3) / 1e12 if dynfwd_ms > 0 else 0.0)
         dom = max(("k_mlp3_fwd", "k_mlp3_bwd", "k_wgrad"), key=lambda k: kern[k]["ms_per_step"])
         d = kern[dom]
         per_launch_flops = fl[dom] / d["launches_per_step"]
@@ -205,41 +357,49 @@ def main():
                         unit="TFLOP/s", traffic=None, avg_launch_ms=avg_ms, launches_per_step=d["launches_per_step"],
                         flops_per_launch=per_launch_flops)
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
-        # HBM bytes of one launch of the dominant kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE passes, committed under profiles/; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note)
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")))
-            fam = [e for e in pm if dom in e["kernel"] and e["fetch_kb_raw"] and e["write_kb"]]
-            if fam and bs == BS:
-                top = max(e["launches"] for e in fam)
-                fam = [e for e in fam if 2 * e["launches"] >= top]          # the train() step's launches of this family
-                n = sum(e["launches"] for e in fam)
-                roofline["traffic"] = sum((2.0 * e["fetch_kb_raw"] + e["write_kb"]) * 1024.0 * e["launches"] for e in fam) / n
-                roofline["traffic_note"] = "PMC launch-weighted mean over " + "; ".join(
-                    f"{e['launches']} x {e['kernel'].strip()} grid {e['grid']}" for e in fam)
-        except Exception:
-            pass
+        # HBM bytes of one launch of the dominant kernel: PMC counters need their own rocprofv3 passes (FETCH_SIZE and
+        # WRITE_SIZE cannot share one, and not with a timing run), so the figure comes from the committed summary of
+        # those passes over this same command (profiles/, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note)
+        for tag in ("r02", "r01_f"):
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
+            except OSError:
+                continue
+            sel = [e for e in pm if dom in e["kernel"] and e["fetch_kb_raw"] and e["write_kb"]]
+            if sel and args.config == "c2" and bs == CONFIGS["c2"]["bs"]:
+                top = max(e["launches"] for e in sel)
+                sel = [e for e in sel if 2 * e["launches"] >= top]          # the train() step's launches of this family
+                n = sum(e["launches"] for e in sel)
+                roofline["traffic"] = sum((2.0 * e["fetch_kb_raw"] + e["write_kb"]) * 1024.0 * e["launches"] for e in sel) / n
+                roofline["traffic_note"] = f"profiles/{tag}_pmc_traffic.json, launch-weighted mean over " + "; ".join(
+                    f"{e['launches']} x {e['kernel'].strip()} grid {e['grid']}" for e in sel)
+            break
+        graph_on = bool(args.graph == 1 or (args.graph == 2 and N < 4096))
         out = {
-            "metric": "transitions/sec", "value": N * world * args.steps / dt, "unit": "transitions/s",
+            "metric": "transitions/sec (minibatch rows through train(), refresh amortised at 1/5000) + grad-steps/sec",
+            "value": N * world * args.steps / dt, "unit": "transitions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"walker2d-friction shapes S={S} A={A}, ensemble 7, rollout_len 1, batch_size {bs}/GPU "
-                                   f"(N={N} rows per train() step: src|tar|fake = {bs}|{bs}|{bs // 2}), fp32 MFMA",
-                       "rows_per_step_per_gpu": N, "parallelism": f"dp{world}",
-                       "hip_graph": bool(args.graph == 1 or (args.graph == 2 and N < 4096))},
+            "config": {"workload": f"{args.config}: {c['label']} (S={S} A={A}, ensemble 7, rollout_len {c['H']}, N={N} rows per "
+                                   f"train() step: src|tar|fake = {bs}|{bs}|{bs // 2}), fp32 MFMA",
+                       "name": args.config, "rows_per_step_per_gpu": N, "parallelism": f"dp{world}", "hip_graph": graph_on},
             "grad_steps_per_sec": args.steps / dt,
-            "rollout_transitions_per_sec": roll_rate, "rollout_ms_per_50000": roll_ms,
-            "rollout_refresh_amortised_ms_per_step": (152000.0 / roll_rate) * 1e3 / 5000.0,
-            "roofline": roofline, "kernels": kern, "final_losses": losses,
+            "grad_steps_per_sec_refresh_excluded": args.steps / dt_steps,
+            "rollout_transitions_per_sec": roll_rate, "rollout_ms_per_call": roll_ms,
+            "rollout_rows_in_timed_region": rolled,
+            "roofline": roofline, "kernels": kern, "final_losses": losses, "replicas_identical": replicas_identical,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, bs)
+            out["cpu_baseline"] = cpu_baseline(c, cfg)
             out["gpu_over_cpu_grad_steps"] = out["grad_steps_per_sec"] / out["cpu_baseline"]["grad_steps_per_sec"]
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
+    if replicas_identical is False:
+        sys.exit(3)
 
 
 if __name__ == "__main__":
