@@ -313,8 +313,10 @@ int64_t mobody_pretrain_workspace(int S, int A, int64_t b);
  * :604-612): member e takes dataset rows idx[e][start + r], r < b.  idx is a DEVICE int32 [7][n_idx] matrix.
  * Outputs: xenc[7][2b][S] (s rows, then s' rows), act[7][b][A], rew[7][b]. */
 int mobody_pretrain_gather(const float* state, const float* action, const float* next_state, const float* reward,
-                           const int32_t* idx, int64_t n_idx, int64_t start, int64_t b, int S, int A, float* xenc,
-                           float* act, float* rew, void* stream);
+                           const int32_t* idx, int64_t n_idx, int64_t start, const int64_t* start_dev, int64_t b, int S,
+                           int A, float* xenc, float* act, float* rew, void* stream);
+/* start_dev (nullable): DEVICE int64 batch counter, start += start_dev[0] * b, so a captured graph walks the index matrix
+ * batch by batch (advance it with mobody_counter_add); reads are clamped to the matrix. */
 
 /* Loss and gradients of one learn() batch (zero_grad + loss.backward, :594-642).  b rows per member on this rank,
  * b_global = rows per member over all data-parallel ranks (gradients / losses are local shares of the global means:
@@ -327,6 +329,14 @@ int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, int use_trg
                           const float* blob, const float* blob_T, const float* xenc, const float* act, const float* rew,
                           const float* noise6, const float* noise7, uint32_t seed, uint32_t call, float* grad,
                           float* loss_out, float* workspace, void* stream);
+
+/* Single-GPU form of mobody_pretrain_grads + mobody_pretrain_adam: every gradient reduction applies the Adam step of the
+ * elements it has just reduced (no gradient blob, four launches fewer).  t_dev (nullable): DEVICE int64[2] = {t_main,
+ * t_za} read instead of the host counts; call_dev (nullable): DEVICE int64 word added to `call` -- both for graph replay. */
+int mobody_pretrain_update(int S, int A, int64_t b, int use_trg, float encoder_loss_coef, float* blob, float* blob_T,
+                           const float* xenc, const float* act, const float* rew, const float* noise6, const float* noise7,
+                           uint32_t seed, uint32_t call, const int64_t* call_dev, float* m, float* v, int64_t t_main,
+                           int64_t t_za, const int64_t* t_dev, float lr, float* loss_out, float* workspace, void* stream);
 
 /* torch.optim.Adam step on the blob (and its T blob): the three MLP regions use the 1-based step count t_main, the
  * action encoder of this step's domain t_za; the other action encoder is skipped (its .grad is None in the reference,

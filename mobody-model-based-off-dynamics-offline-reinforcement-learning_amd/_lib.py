@@ -106,7 +106,9 @@ PROTOTYPES = {
     "mobody_pretrain_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(MobodyPretrainLayout)]),
     "mobody_pretrain_transpose": (C.c_int, [C.c_int, C.c_int, vp, vp, vp]),
     "mobody_pretrain_workspace": (i64, [C.c_int, C.c_int, i64]),
-    "mobody_pretrain_gather": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "mobody_pretrain_gather": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, vp, i64, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "mobody_pretrain_update": (C.c_int, [C.c_int, C.c_int, i64, C.c_int, f32, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp,
+                                         vp, i64, i64, vp, f32, vp, vp, vp]),
     "mobody_pretrain_grads": (C.c_int, [C.c_int, C.c_int, i64, i64, C.c_int, f32, vp, vp, vp, vp, vp, vp, vp, u32, u32,
                                         vp, vp, vp, vp]),
     "mobody_pretrain_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, i64, i64, f32, f32, vp]),

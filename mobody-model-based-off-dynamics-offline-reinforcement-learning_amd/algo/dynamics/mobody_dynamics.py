@@ -63,7 +63,11 @@ class MOBODYEnsembleDynamics(object):
         self.noise_fn = None          # optional hook: noise_fn((7, B, S)) -> unit normals (tests)
         self.train_noise_fn = None    # optional hook: b -> (noise6[6,7,b,16], noise7[7,b,S]) device tensors (tests)
         self._ws = None
-        self._pre_ws, self._train_calls = None, 0
+        self._pre_ws_by_b, self._train_calls = {}, 0
+        self.train_graph = int(config.get("train_graph", 1))   # replay full pre-training batches as one HIP graph (1 GPU, device noise)
+        self._pre_graphs = {}
+        self._pre_ctr = torch.zeros(4, dtype=torch.int64, device=model.device)
+        self._pre_acc = torch.zeros(5, dtype=torch.float32, device=model.device)
         self._pre_loss = torch.zeros(5, dtype=torch.float32, device=model.device)
         task_id = getattr(terminal_fn, "task_id", None)
         if task_id is None:
@@ -135,8 +139,7 @@ class MOBODYEnsembleDynamics(object):
         m = self.model
         st = m.train_state()
         S, A = m.obs_dim, m.action_dim
-        if self._pre_ws is None or self._pre_ws[0] != b:
-            self._pre_ws = (b, ops.pretrain_workspace(S, A, max(b, 1), m.device))
+        ws = self._ws_for(max(b, 1))
         self._train_calls += 1
         n6 = n7 = None
         if self.train_noise_fn is not None:
@@ -144,7 +147,7 @@ class MOBODYEnsembleDynamics(object):
         world, _ = self._world()
         if b > 0:
             ops.pretrain_grads(S, A, b, use_trg, self.encoder_loss_coef, st["blob"], st["blob_T"], xenc, act, rew, st["grad"],
-                               self._pre_loss, self._pre_ws[1], noise6=n6, noise7=n7,
+                               self._pre_loss, ws, noise6=n6, noise7=n7,
                                seed=(self.seed + 77 + dp.rank_salt()) & 0xFFFFFFFF, call=self._train_calls, b_global=b_global)
         else:                                             # data parallel: this rank has no row of a ragged last batch
             st["grad"].zero_(); self._pre_loss.zero_()
@@ -156,6 +159,73 @@ class MOBODYEnsembleDynamics(object):
                           st["t_za"][bool(use_trg)], self._lr())
         m.mark_trained()
         return self._pre_loss
+
+    def _ws_for(self, b):
+        if b not in self._pre_ws_by_b:
+            self._pre_ws_by_b[b] = ops.pretrain_workspace(self.model.obs_dim, self.model.action_dim, b, self.model.device)
+        return self._pre_ws_by_b[b]
+
+    def _learn_batch_fused(self, use_trg, xenc, act, rew, b):
+        """Single-GPU form of _learn_batch: the gradient reductions apply Adam themselves (mobody_pretrain_update)."""
+        m = self.model
+        st = m.train_state()
+        S, A = m.obs_dim, m.action_dim
+        ws = self._ws_for(b)
+        self._train_calls += 1
+        n6 = n7 = None
+        if self.train_noise_fn is not None:
+            n6, n7 = self.train_noise_fn(b)
+        st["t_main"] += 1; st["t_za"][bool(use_trg)] += 1
+        ops.pretrain_update(S, A, b, use_trg, self.encoder_loss_coef, st["blob"], st["blob_T"], xenc, act, rew, st["m"], st["v"],
+                            st["t_main"], st["t_za"][bool(use_trg)], self._lr(), self._pre_loss, ws, noise6=n6,
+                            noise7=n7, seed=(self.seed + 77) & 0xFFFFFFFF, call=self._train_calls)
+        m.mark_trained()
+        return self._pre_loss
+
+    def _learn_graph(self, use_trg, data, idx, batch_size, n_full):
+        """`n_full` full batches of one pass as replays of ONE captured HIP graph (gather + forward + backward + fused Adam,
+        ~22 launches): the batch offset into the bootstrap matrix, the noise call id and the Adam step counts live in
+        device words that the graph advances itself.  Device-RNG noise only.  Returns the summed loss vector."""
+        m = self.model
+        st = m.train_state()
+        S, A, b, dev = m.obs_dim, m.action_dim, batch_size, m.device
+        d = bool(use_trg)
+        ws = self._ws_for(b)
+        key = (d, b, data[0].data_ptr(), idx.data_ptr(), idx.shape[1], st["blob"].data_ptr(), ws.data_ptr())
+        c = self._pre_ctr                                  # [batch index, call, t_main, t_za]: one launch advances all four
+        c.copy_(torch.tensor([-1, self._train_calls, st["t_main"], st["t_za"][d]], dtype=torch.int64), non_blocking=False)
+        self._pre_acc.zero_()
+        if key not in self._pre_graphs:
+            bufs = (torch.empty(7, 2 * b, S, dtype=torch.float32, device=dev), torch.empty(7, b, A, dtype=torch.float32, device=dev),
+                    torch.empty(7, b, dtype=torch.float32, device=dev))
+
+            def body():
+                ops.counter_add(c, 1)
+                ops.pretrain_gather(data[0], data[1], data[2], data[3], idx, 0, b, out=bufs, start_dev=c[0:1])
+                ops.pretrain_update(S, A, b, d, self.encoder_loss_coef, st["blob"], st["blob_T"], bufs[0], bufs[1], bufs[2],
+                                    st["m"], st["v"], 1, 1, self._lr(), self._pre_loss, ws,
+                                    seed=(self.seed + 77) & 0xFFFFFFFF, call=0, call_dev=c[1:2], t_dev=c[2:4])
+                self._pre_acc.add_(self._pre_loss)
+
+            for k in [k for k in self._pre_graphs if k[:2] == key[:2]]:     # a stale graph of this domain / batch size
+                del self._pre_graphs[k]
+            body()                                        # warm-up (eager) step counts as batch 0
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            self._pre_graphs[key] = (g, bufs)
+            first = 1                                     # (capturing executes nothing: the device counters only move when kernels run)
+        else:
+            first = 0
+        g = self._pre_graphs[key][0]
+        for _ in range(n_full - first):
+            g.replay()
+        self._train_calls += n_full
+        st["t_main"] += n_full; st["t_za"][d] += n_full
+        self.total_steps = getattr(self, "total_steps", 0) + n_full
+        m.mark_trained()
+        return self._pre_acc
 
     def _learn_loop(self, n, batch_size, step):
         """learn()'s batch loop (:604-650): `step(start, rows)` runs one batch and returns the device loss vector; the
@@ -195,14 +265,29 @@ class MOBODYEnsembleDynamics(object):
         """learn() on a device-resident data set with a [7, n] bootstrap index matrix: the batch rows are gathered by a
         kernel straight into the layout the forward pass reads (the reference gathers [7, n, .] copies on the host every
         epoch and ships each batch over PCIe, :604-612)."""
+        world, _ = self._world()
+
         def step(start, rows):
             lo, b = self._shard(start, rows)
             if b == 0:
                 return self._learn_batch(use_trg, None, None, None, 0, rows)
             xenc, act, rew = ops.pretrain_gather(data[0], data[1], data[2], data[3], idx, lo, b)
+            if world == 1:
+                return self._learn_batch_fused(use_trg, xenc, act, rew, b)
             return self._learn_batch(use_trg, xenc, act, rew, b, rows)
 
-        return self._learn_loop(idx.shape[1], batch_size, step)
+        n = idx.shape[1]
+        n_full = n // batch_size
+        if world == 1 and self.train_graph and self.train_noise_fn is None and n_full >= 3:
+            self.model.training = True
+            acc = self._learn_graph(use_trg, data, idx, batch_size, n_full).clone()
+            n_batch = n_full
+            if n % batch_size:                              # ragged last batch: eager
+                self.total_steps += 1
+                acc += step(n_full * batch_size, n - n_full * batch_size)
+                n_batch += 1
+            return tuple(float(x) for x in (acc / n_batch).tolist())
+        return self._learn_loop(n, batch_size, step)
 
     @torch.no_grad()
     def validate(self, use_trg_data, holdout_obss, holdout_actions, holdout_next_obss, holdout_rewards):
@@ -265,18 +350,18 @@ class MOBODYEnsembleDynamics(object):
         n_s, n_t = n_src - src_hold, n_trg - trg_hold
         E = m.num_ensemble
         trg_holdout_losses = [1e10 for _ in range(E)]
-        src_idx = bc(torch.randint(n_s, size=[E, n_s]).to(device=dev, dtype=torch.int32))   # :826-827 (CPU generator)
-        trg_idx = bc(torch.randint(n_t, size=[E, n_t]).to(device=dev, dtype=torch.int32))
+        src_idx = bc(torch.randint(n_s, size=[E, n_s]).to(device=dev, dtype=torch.int32)).contiguous()   # :826-827 (CPU generator)
+        trg_idx = bc(torch.randint(n_t, size=[E, n_t]).to(device=dev, dtype=torch.int32)).contiguous()
         epoch, cnt = 0, 0
         self.history = []
         while True:
             epoch += 1
             self.epoch = epoch
-            src_stats = self._learn_indexed(False, src_tr, src_idx.contiguous(), batch_size)              # :873-878
+            src_stats = self._learn_indexed(False, src_tr, src_idx, batch_size)              # :873-878
             src_val, _ = self.validate(False, *src_ho)
             src_holdout_loss = float(np.sort(src_val)[:m.num_elites].mean())
             for _ in range(3):                                                              # :897-907
-                trg_stats = self._learn_indexed(True, trg_tr, trg_idx.contiguous(), batch_size)
+                trg_stats = self._learn_indexed(True, trg_tr, trg_idx, batch_size)
             trg_val, trg_enc = self.validate(True, *trg_ho)
             trg_holdout_loss = float(np.sort(trg_val)[:m.num_elites].mean())
             self.history.append(dict(epoch=epoch, src=src_stats, trg=trg_stats, src_holdout=src_holdout_loss,
@@ -289,8 +374,8 @@ class MOBODYEnsembleDynamics(object):
                 writer.add_scalar("trg_loss/dynamics_train_loss", trg_stats[1], global_step=epoch)
                 writer.add_scalar("trg_loss/dynamics_encoder_loss", trg_stats[2], global_step=epoch)
                 writer.add_scalar("trg_loss/dynamics_holdout_loss", trg_holdout_loss, global_step=epoch)
-            src_idx = bc(self.shuffle_rows(src_idx).contiguous())                           # :934-935
-            trg_idx = bc(self.shuffle_rows(trg_idx).contiguous())
+            src_idx.copy_(bc(self.shuffle_rows(src_idx).contiguous()))                      # :934-935 (in place: the captured
+            trg_idx.copy_(bc(self.shuffle_rows(trg_idx).contiguous()))                      #  graphs keep reading these tensors)
             indexes = []
             for i, new_loss, old_loss in zip(range(E), trg_val, trg_holdout_losses):        # :937-942
                 if (old_loss - new_loss) / old_loss > 0.01:

@@ -472,6 +472,9 @@ class MOBODY(object):
     def _graph_step(self, src, tar, batch_size):
         world = self._world()
         segmented = world > 1 or (self._force_segments and torch.distributed.is_initialized())
+        if segmented and self.dp_graph == "captured" and torch.distributed.get_backend() != "nccl":
+            self.dp_graph = "segments"                  # only RCCL collectives can be recorded into a HIP graph (gloo stages
+                                                        # through the host; a refused capture leaves the stream unusable)
         # every device pointer the captured kernels read or write: a reloaded checkpoint, a re-assigned fake buffer
         # or a resized minibatch must force a re-capture (replaying against freed tensors corrupts memory silently)
         fb = self.fake_replay_buffer

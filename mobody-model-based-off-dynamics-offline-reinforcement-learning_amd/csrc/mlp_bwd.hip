@@ -438,6 +438,8 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
 // WAVE per entry strides over the row-tile partials and shuffle-reduces (a serial loop over ~160 dependent
 // L2 reads per thread made the first version of this kernel latency bound: 41 us instead of ~5).
 __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
+  __shared__ float adam_sm[2];
+  adam_block_consts(a.adam, adam_sm);
   const long long nW = a.L.total_floats;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid < nW) {
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
     }
     for (; k < a.nsplit; ++k) s += a.slabs[(long long)k * a.slab_stride + j];
     if (a.grad != nullptr) a.grad[j] = s;
-    if (a.adam.on) adam_element(a.adam, a.L, j, s);
+    if (a.adam.on) adam_element(a.adam, a.L, j, s, adam_sm);
     return;
   }
   // ---- bias part: wave index -> (member, bias element) ----
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
   if (lane == 0) {
     const long long dst = (long long)m * a.L.member_floats + (off < HID ? a.L.b1 + off : off < 2 * HID ? a.L.b2 + (off - HID) : a.L.b3 + (off - 2 * HID));
     if (a.grad != nullptr) a.grad[dst] = s;
-    if (a.adam.on) adam_element(a.adam, a.L, dst, s);
+    if (a.adam.on) adam_element(a.adam, a.L, dst, s, adam_sm);
   }
 }
 

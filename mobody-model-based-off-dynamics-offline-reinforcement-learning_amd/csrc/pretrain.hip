@@ -123,6 +123,7 @@ struct PreRow {
   const float* noise6;       // [6][E][b][16] z1(s) z2(s') z3(s) z4(s') z5(s) z6(s), or null -> Philox
   const float* noise7;       // [E][b][S], or null -> Philox
   uint32_t seed, call;
+  const long long* call_dev; // optional device word added to `call` (graph replay: the step counter lives on the device)
   const float* za;           // the action encoder in use: [E][za_member_floats]
   long long za_mf, za_w1, za_b1, za_w2, za_b2;
   const float* enc_out;      // [E][2b][32]  mu | logvar
@@ -143,97 +144,116 @@ struct PreLossOff { long long lat, rt, rw; int n_lat, n_rt, n_rw; };
 
 __device__ __forceinline__ float pre_noise(const PreRow& a, int k, int e, long long row, int j, int width) {
   const long long i = ((long long)e * a.b + row) * width + j;
-  if (k < 6) return a.noise6 ? a.noise6[(long long)k * NENS * a.b * 16 + i] : rng_normal_at(a.seed, STREAM_PRE + k, a.call, (uint64_t)i);
-  return a.noise7 ? a.noise7[i] : rng_normal_at(a.seed, STREAM_PRE + 6, a.call, (uint64_t)i);
+  if (k < 6 && a.noise6) return a.noise6[(long long)k * NENS * a.b * 16 + i];
+  if (k == 6 && a.noise7) return a.noise7[i];
+  const uint32_t call = a.call + (a.call_dev ? (uint32_t)a.call_dev[0] : 0u);
+  return rng_normal_at(a.seed, STREAM_PRE + k, call, (uint64_t)i);
 }
 __device__ __forceinline__ float swishf(float z) { return z / (1.f + expf(-z)); }
 __device__ __forceinline__ float dswishf(float z) { const float s = 1.f / (1.f + expf(-z)); return s * (1.f + z * (1.f - s)); }
 
-// stage the member's action encoder in LDS: W1[za_in][32] b1[32] W2[32][16] b2[16]
-__device__ __forceinline__ void za_stage(const PreRow& a, int e, float* sw) {
+// ---- latent level: cooperative kernels, one workgroup = LROWS rows of one member ------------------------------------
+// Everything between the state encoder's (mu, logvar) and the decoder's inputs is 16..32-wide work per row: six
+// reparameterisation samples, three passes through the action encoder (16+A -> 32 -> 16), KL and latent-consistency terms.
+// A thread-per-row formulation runs ~10 k dependent instructions on a few thousand threads (measured 46 + 89 us per step
+// at b = 256, the two longest kernels of the step); here each phase is spread over the 256 threads of the workgroup
+// through LDS and the grid is (ceil(b / 8), 7) workgroups.
+constexpr int LROWS = 8, LP = 3 * LROWS;     // rows per workgroup; (pass, row) pairs: pass 0,1,2 = the samples z3, z5, z6
+
+struct LatentLds {                           // float offsets inside the dynamic LDS block
+  int sw, es, es2, act, z, eps, sdv, pre, hh, za, dout, dpre, du, total;
+};
+__host__ __device__ inline LatentLds latent_lds(long long za_mf, int A) {
+  LatentLds o; int t = 0;
+  auto take = [&](int n) { const int r = t; t += (n + 3) & ~3; return r; };
+  o.sw = take((int)za_mf); o.es = take(LROWS * 32); o.es2 = take(LROWS * 32); o.act = take(LROWS * A);
+  o.z = take(LP * LATENT); o.eps = take(LP * LATENT); o.sdv = take(LP * LATENT); o.pre = take(LP * ZH); o.hh = take(LP * ZH);
+  o.za = take(LP * LATENT); o.dout = take(LP * LATENT); o.dpre = take(LP * ZH); o.du = take(LP * LATENT);
+  o.total = t;
+  return o;
+}
+
+// phases 0..C: weights, (mu, logvar) rows, actions -> samples Z, hidden pre-activations PRE / activations HH, outputs ZA
+__device__ __forceinline__ void latent_forward(const PreRow& a, const LatentLds& o, float* sh, int e, long long row0) {
+  const int tid = threadIdx.x;
   const float* g = a.za + (long long)e * a.za_mf;
-  for (int i = threadIdx.x; i < (int)a.za_mf; i += blockDim.x) sw[i] = g[i];
-}
-
-// forward of the action encoder for one row: z[16], action row -> pre[32], za[16]   (encode_*_action :245-271, mu half)
-__device__ __forceinline__ void za_forward(const PreRow& a, const float* sw, const float (&z)[LATENT], const float* arow,
-                                           float (&pre)[ZH], float (&za)[LATENT]) {
-  const float *W1 = sw + a.za_w1, *b1 = sw + a.za_b1, *W2 = sw + a.za_w2, *b2 = sw + a.za_b2;
-#pragma unroll
-  for (int n = 0; n < ZH; ++n) pre[n] = b1[n];
-#pragma unroll
-  for (int j = 0; j < LATENT; ++j)
-#pragma unroll
-    for (int n = 0; n < ZH; ++n) pre[n] += z[j] * W1[j * ZH + n];
-  for (int j = 0; j < a.A; ++j) {
-    const float aj = arow[j];
-#pragma unroll
-    for (int n = 0; n < ZH; ++n) pre[n] += aj * W1[(LATENT + j) * ZH + n];
+  for (int i = tid; i < (int)a.za_mf; i += 256) sh[o.sw + i] = g[i];
+  {
+    const int r = tid >> 5, c = tid & 31;                                   // 8 rows x 32 columns = 256 threads
+    const long long rc = min(row0 + r, a.b - 1);
+    sh[o.es + tid] = a.enc_out[((long long)e * 2 * a.b + rc) * 32 + c];
+    sh[o.es2 + tid] = a.enc_out[((long long)e * 2 * a.b + a.b + rc) * 32 + c];
   }
-#pragma unroll
-  for (int j = 0; j < LATENT; ++j) za[j] = b2[j];
-#pragma unroll
-  for (int n = 0; n < ZH; ++n) {
-    const float h = swishf(pre[n]);
-#pragma unroll
-    for (int j = 0; j < LATENT; ++j) za[j] += h * W2[n * LATENT + j];
+  for (int i = tid; i < LROWS * a.A; i += 256) {
+    const int r = i / a.A, c = i - r * a.A;
+    sh[o.act + i] = a.act[((long long)e * a.b + min(row0 + r, a.b - 1)) * a.A + c];
   }
-}
-
-// grid (ceil(b/32), E), 128 threads = 32 rows x 4 slots: slots 0..2 = the samples z3, z5, z6 through the action encoder,
-// slot 3 = z1, z2 and the KL sums.
-__global__ __launch_bounds__(128) void k_pre_latent_fwd(PreRow a, PreLossOff lo) {
-  extern __shared__ __attribute__((aligned(16))) float sw[];
-  __shared__ float red[2][2];
-  const int e = blockIdx.y, r = threadIdx.x & 31, slot = threadIdx.x >> 5;
-  const long long row = (long long)blockIdx.x * 32 + r;
-  const bool ok = row < a.b;
-  const long long rc = ok ? row : 0;
-  za_stage(a, e, sw);
   __syncthreads();
-  const float* eo = a.enc_out + ((long long)e * 2 * a.b + rc) * 32;           // s row
-  const float* eo2 = a.enc_out + ((long long)e * 2 * a.b + a.b + rc) * 32;    // s' row
+  for (int i = tid; i < LP * LATENT; i += 256) {                            // A: z_k = mu + eps_k * exp(logvar / 2)
+    const int p = i >> 4, j = i & 15, pass = p / LROWS, r = p - pass * LROWS;
+    const int k = pass == 0 ? 2 : pass == 1 ? 4 : 5;
+    const float eps = pre_noise(a, k, e, min(row0 + r, a.b - 1), j, 16);
+    const float sd = expf(0.5f * sh[o.es + r * 32 + LATENT + j]);
+    sh[o.eps + i] = eps; sh[o.sdv + i] = sd; sh[o.z + i] = sh[o.es + r * 32 + j] + eps * sd;
+  }
+  __syncthreads();
+  const float *W1 = sh + o.sw + a.za_w1, *b1 = sh + o.sw + a.za_b1, *W2 = sh + o.sw + a.za_w2, *b2 = sh + o.sw + a.za_b2;
+  for (int i = tid; i < LP * ZH; i += 256) {                                // B: hidden layer on [z, a]
+    const int p = i >> 5, n = i & 31, r = p % LROWS;
+    float acc = b1[n];
+#pragma unroll
+    for (int j = 0; j < LATENT; ++j) acc += sh[o.z + p * LATENT + j] * W1[j * ZH + n];
+    for (int j = 0; j < a.A; ++j) acc += sh[o.act + r * a.A + j] * W1[(LATENT + j) * ZH + n];
+    sh[o.pre + i] = acc; sh[o.hh + i] = swishf(acc);
+  }
+  __syncthreads();
+  for (int i = tid; i < LP * LATENT; i += 256) {                            // C: output layer, mu half
+    const int p = i >> 4, j = i & 15;
+    float acc = b2[j];
+#pragma unroll
+    for (int n = 0; n < ZH; ++n) acc += sh[o.hh + p * ZH + n] * W2[n * LATENT + j];
+    sh[o.za + i] = acc;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_pre_latent_fwd(PreRow a, PreLossOff lo, LatentLds o) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  __shared__ float red[8];
+  const int e = blockIdx.y, tid = threadIdx.x;
+  const long long row0 = (long long)blockIdx.x * LROWS, b = a.b;
+  latent_forward(a, o, sh, e, row0);
   float lat = 0.f, kl = 0.f;
-  if (slot < 3) {
-    const int k = slot == 0 ? 2 : slot == 1 ? 4 : 5;
-    float z[LATENT], pre[ZH], za[LATENT];
-#pragma unroll
-    for (int j = 0; j < LATENT; ++j) z[j] = eo[j] + pre_noise(a, k, e, rc, j, 16) * expf(0.5f * eo[LATENT + j]);
-    za_forward(a, sw, z, a.act + ((long long)e * a.b + rc) * a.A, pre, za);
-    if (slot == 0) {                                  // latent consistency against z4 = sample of s' (no gradient, :323-326)
-#pragma unroll
-      for (int j = 0; j < LATENT; ++j) {
-        const float z4 = eo2[j] + pre_noise(a, 3, e, rc, j, 16) * expf(0.5f * eo2[LATENT + j]);
-        const float d = (z[j] + za[j]) - z4;
-        lat += ok ? d * d : 0.f;
-      }
-    } else if (ok) {
-      float* o = a.zt + ((long long)e * 4 * a.b + (slot == 1 ? 2 : 3) * a.b + row) * LATENT;
-#pragma unroll
-      for (int j = 0; j < LATENT; ++j) o[j] = z[j] + za[j];
-    }
-  } else {
-    float* o1 = a.zt + ((long long)e * 4 * a.b + rc) * LATENT;
-    float* o2 = a.zt + ((long long)e * 4 * a.b + a.b + rc) * LATENT;
-#pragma unroll
-    for (int j = 0; j < LATENT; ++j) {
-      const float mu = eo[j], lv = eo[LATENT + j], mu2 = eo2[j], lv2 = eo2[LATENT + j];
-      const float z1 = mu + pre_noise(a, 0, e, rc, j, 16) * expf(0.5f * lv);
-      const float z2 = mu2 + pre_noise(a, 1, e, rc, j, 16) * expf(0.5f * lv2);
-      if (ok) { o1[j] = z1; o2[j] = z2; }
-      const float t = -0.5f * (1.f + lv - mu * mu - expf(lv)) + -0.5f * (1.f + lv2 - mu2 * mu2 - expf(lv2));   // :332-335
-      kl += ok ? t : 0.f;
+  {                                                      // passes 1, 2 -> decoder inputs (quarters 2, 3): 2 x 8 x 16 = 256 elements
+    const int pass = 1 + (tid >> 7), r = (tid >> 4) & 7, j = tid & 15, p = pass * LROWS + r;
+    if (row0 + r < b) a.zt[((long long)e * 4 * b + (pass + 1) * b + row0 + r) * LATENT + j] = sh[o.z + p * LATENT + j] + sh[o.za + p * LATENT + j];
+  }
+  if (tid < 128) {                                       // pass 0 against z4, the no-grad sample of s' (:323-326)
+    const int r = tid >> 4, j = tid & 15;
+    const long long rc = min(row0 + r, b - 1);
+    const float z4 = sh[o.es2 + r * 32 + j] + pre_noise(a, 3, e, rc, j, 16) * expf(0.5f * sh[o.es2 + r * 32 + LATENT + j]);
+    const float d = (sh[o.z + r * LATENT + j] + sh[o.za + r * LATENT + j]) - z4;
+    lat = row0 + r < b ? d * d : 0.f;
+  } else {                                               // z1, z2 -> quarters 0, 1 and the two KL sums (:332-335)
+    const int r = (tid - 128) >> 4, j = tid & 15;
+    const long long rc = min(row0 + r, b - 1);
+    const float mu = sh[o.es + r * 32 + j], lv = sh[o.es + r * 32 + LATENT + j];
+    const float mu2 = sh[o.es2 + r * 32 + j], lv2 = sh[o.es2 + r * 32 + LATENT + j];
+    const float z1 = mu + pre_noise(a, 0, e, rc, j, 16) * expf(0.5f * lv);
+    const float z2 = mu2 + pre_noise(a, 1, e, rc, j, 16) * expf(0.5f * lv2);
+    if (row0 + r < b) {
+      a.zt[((long long)e * 4 * b + row0 + r) * LATENT + j] = z1;
+      a.zt[((long long)e * 4 * b + b + row0 + r) * LATENT + j] = z2;
+      kl = -0.5f * (1.f + lv - mu * mu - expf(lv)) + -0.5f * (1.f + lv2 - mu2 * mu2 - expf(lv2));
     }
   }
-  // loss partials of this workgroup: slot 0 (wave 0, lanes 0..31) holds the latent terms, slot 3 (wave 1, lanes 32..63) the KL
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) { lat += __shfl_xor(lat, o); kl += __shfl_xor(kl, o); }
-  if (threadIdx.x == 0) red[0][0] = lat;
-  if (threadIdx.x == 96) red[1][1] = kl;
+  for (int s = 32; s > 0; s >>= 1) { lat += __shfl_xor(lat, s); kl += __shfl_xor(kl, s); }
+  if ((tid & 63) == 0) { red[tid >> 6] = lat; red[4 + (tid >> 6)] = kl; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float* p = a.lossp + lo.lat + ((long long)e * gridDim.x + blockIdx.x) * 2;
-    p[0] = red[0][0]; p[1] = red[1][1];
+  if (tid == 0) {
+    float* q = a.lossp + lo.lat + ((long long)e * gridDim.x + blockIdx.x) * 2;
+    q[0] = red[0] + red[1]; q[1] = red[6] + red[7];
   }
 }
 
@@ -334,127 +354,118 @@ __global__ __launch_bounds__(256) void k_pre_fake_bwd(PreRow a) {
   }
 }
 
-// grid (ceil(b/32), E), 128 threads = 32 rows x 4 slots (as k_pre_latent_fwd).  Recomputes the action-encoder forward,
-// runs its backward, reduces the four slots' d mu / d logvar contributions into the state encoder's output gradient and
-// accumulates the action encoder's weight-gradient partials of the workgroup.
-__global__ __launch_bounds__(128) void k_pre_latent_bwd(PreRow a, int za_in) {
+// Backward of the latent level (same workgroup shape as k_pre_latent_fwd): recomputes the action-encoder forward, runs its
+// backward, reduces the d mu / d logvar contributions of the four uses of the s row (z1, z3, z5, z6) and of z2 for the
+// s' row into the state encoder's output gradient, and accumulates the action encoder's weight-gradient partials.
+__global__ __launch_bounds__(256) void k_pre_latent_bwd(PreRow a, LatentLds o, int za_in) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
-  const int e = blockIdx.y, r = threadIdx.x & 31, slot = threadIdx.x >> 5;
-  const long long row = (long long)blockIdx.x * 32 + r, b = a.b;
-  const bool ok = row < b;
-  const long long rc = ok ? row : 0;
-  float* sw = sh;                                        // weights            [za_mf]
-  float* U = sw + ((a.za_mf + 3) & ~3LL);                // inputs [z, a]      [96][za_in]
-  float* DP = U + 96 * za_in;                            // d pre-activation   [96][32]
-  float* Hh = DP + 96 * ZH;                              // hidden activation  [96][32]
-  float* DO = Hh + 96 * ZH;                              // d output           [96][16]
-  float* DM = DO + 96 * LATENT;                          // per-slot d mu | d logvar of the s row  [4][32][32]
-  za_stage(a, e, sw);
-  __syncthreads();
-  const float* eo = a.enc_out + ((long long)e * 2 * b + rc) * 32;
-  const float* eo2 = a.enc_out + ((long long)e * 2 * b + b + rc) * 32;
-  float dmu[LATENT], dlv[LATENT];
-  if (slot < 3) {
-    const int k = slot == 0 ? 2 : slot == 1 ? 4 : 5;
-    const float *W1 = sw + a.za_w1, *W2 = sw + a.za_w2;
-    float z[LATENT], eps[LATENT], sdv[LATENT], pre[ZH], za[LATENT], dout[LATENT];
-#pragma unroll
-    for (int j = 0; j < LATENT; ++j) {
-      eps[j] = pre_noise(a, k, e, rc, j, 16);
-      sdv[j] = expf(0.5f * eo[LATENT + j]);
-      z[j] = eo[j] + eps[j] * sdv[j];
-    }
-    const float* arow = a.act + ((long long)e * b + rc) * a.A;
-    za_forward(a, sw, z, arow, pre, za);
-    if (slot == 0) {
-      const float cl = a.ce * 2.f * a.inv_bg / (float)LATENT;
-#pragma unroll
-      for (int j = 0; j < LATENT; ++j) {
-        const float z4 = eo2[j] + pre_noise(a, 3, e, rc, j, 16) * expf(0.5f * eo2[LATENT + j]);
-        dout[j] = ok ? cl * ((z[j] + za[j]) - z4) : 0.f;
-      }
+  const int e = blockIdx.y, tid = threadIdx.x;
+  const long long row0 = (long long)blockIdx.x * LROWS, b = a.b;
+  latent_forward(a, o, sh, e, row0);
+  const float *W1 = sh + o.sw + a.za_w1, *W2 = sh + o.sw + a.za_w2;
+  for (int i = tid; i < LP * LATENT; i += 256) {                            // D: d loss / d (z_k + za_k)
+    const int p = i >> 4, j = i & 15, pass = p / LROWS, r = p - pass * LROWS;
+    const bool ok = row0 + r < b;
+    const long long rc = min(row0 + r, b - 1);
+    float d;
+    if (pass == 0) {
+      const float z4 = sh[o.es2 + r * 32 + j] + pre_noise(a, 3, e, rc, j, 16) * expf(0.5f * sh[o.es2 + r * 32 + LATENT + j]);
+      d = a.ce * 2.f * a.inv_bg / (float)LATENT * ((sh[o.z + i] + sh[o.za + i]) - z4);
     } else {
-      const float* g = a.dzt + ((long long)e * 4 * b + (slot == 1 ? 2 : 3) * b + rc) * LATENT;
-#pragma unroll
-      for (int j = 0; j < LATENT; ++j) dout[j] = ok ? g[j] : 0.f;
+      d = a.dzt[((long long)e * 4 * b + (pass + 1) * b + rc) * LATENT + j];
     }
-    const int q = slot * 32 + r;                         // (row, pass) slot of this thread in the staging arrays
-    float du[LATENT];
-#pragma unroll
-    for (int j = 0; j < LATENT; ++j) { du[j] = 0.f; DO[q * LATENT + j] = dout[j]; U[q * za_in + j] = z[j]; }
-    for (int j = 0; j < a.A; ++j) U[q * za_in + LATENT + j] = arow[j];
-#pragma unroll
-    for (int n = 0; n < ZH; ++n) {
-      float dh = 0.f;
-#pragma unroll
-      for (int j = 0; j < LATENT; ++j) dh += W2[n * LATENT + j] * dout[j];
-      const float dp = dh * dswishf(pre[n]);
-      DP[q * ZH + n] = dp;
-      Hh[q * ZH + n] = swishf(pre[n]);
-#pragma unroll
-      for (int j = 0; j < LATENT; ++j) du[j] += W1[j * ZH + n] * dp;
-    }
-#pragma unroll
-    for (int j = 0; j < LATENT; ++j) {
-      const float dz = dout[j] + du[j];                  // z_k feeds the sum z_k + za(z_k, a) and the encoder input
-      dmu[j] = dz; dlv[j] = dz * 0.5f * eps[j] * sdv[j];
-    }
-  } else {
-    const float ckl = a.ce * 0.05f * a.inv_bg / (float)LATENT;
-    const float* g1 = a.dzt + ((long long)e * 4 * b + rc) * LATENT;
-    const float* g2 = a.dzt + ((long long)e * 4 * b + b + rc) * LATENT;
-    float* o2 = a.dz3enc + ((long long)e * 2 * b + b + rc) * 32;
-#pragma unroll
-    for (int j = 0; j < LATENT; ++j) {
-      const float mu = eo[j], lv = eo[LATENT + j], mu2 = eo2[j], lv2 = eo2[LATENT + j];
-      const float dz1 = ok ? g1[j] : 0.f, dz2 = ok ? g2[j] : 0.f;
-      dmu[j] = dz1 + ckl * mu;
-      dlv[j] = dz1 * 0.5f * pre_noise(a, 0, e, rc, j, 16) * expf(0.5f * lv) + ckl * (-0.5f) * (1.f - expf(lv));
-      if (ok) {                                          // s' row: only z2 and its KL term carry a gradient
-        o2[j] = dz2 + ckl * mu2;
-        o2[LATENT + j] = dz2 * 0.5f * pre_noise(a, 1, e, rc, j, 16) * expf(0.5f * lv2) + ckl * (-0.5f) * (1.f - expf(lv2));
-      }
-    }
+    sh[o.dout + i] = ok ? d : 0.f;
   }
-#pragma unroll
-  for (int j = 0; j < LATENT; ++j) { DM[(slot * 32 + r) * 32 + j] = dmu[j]; DM[(slot * 32 + r) * 32 + LATENT + j] = dlv[j]; }
   __syncthreads();
-  if (ok) {                                              // 4 slots x 8 outputs each, summed in slot order
-    float* o = a.dz3enc + ((long long)e * 2 * b + row) * 32;
+  for (int i = tid; i < LP * ZH; i += 256) {                                // E: through the output layer and Swish
+    const int p = i >> 5, n = i & 31;
+    float dh = 0.f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int col = slot * 8 + c;
-      o[col] = ((DM[(0 * 32 + r) * 32 + col] + DM[(1 * 32 + r) * 32 + col]) + DM[(2 * 32 + r) * 32 + col]) + DM[(3 * 32 + r) * 32 + col];
+    for (int j = 0; j < LATENT; ++j) dh += W2[n * LATENT + j] * sh[o.dout + p * LATENT + j];
+    sh[o.dpre + i] = dh * dswishf(sh[o.pre + i]);
+  }
+  __syncthreads();
+  for (int i = tid; i < LP * LATENT; i += 256) {                            // F: d z_k = d out + (W1 d pre)[:16]
+    const int p = i >> 4, j = i & 15;
+    float du = sh[o.dout + i];
+#pragma unroll
+    for (int n = 0; n < ZH; ++n) du += W1[j * ZH + n] * sh[o.dpre + p * ZH + n];
+    sh[o.du + i] = du;
+  }
+  __syncthreads();
+  {                                                                         // G: encoder output gradients, 8 rows x 32 columns
+    const int r = tid >> 5, c = tid & 31, j = c & 15;
+    const long long rc = min(row0 + r, b - 1);
+    const float ckl = a.ce * 0.05f * a.inv_bg / (float)LATENT;
+    const float mu = sh[o.es + r * 32 + j], lv = sh[o.es + r * 32 + LATENT + j];
+    const float mu2 = sh[o.es2 + r * 32 + j], lv2 = sh[o.es2 + r * 32 + LATENT + j];
+    const float dz1 = a.dzt[((long long)e * 4 * b + rc) * LATENT + j], dz2 = a.dzt[((long long)e * 4 * b + b + rc) * LATENT + j];
+    float v, v2;
+    if (c < LATENT) {
+      v = ((sh[o.du + r * LATENT + j] + sh[o.du + (LROWS + r) * LATENT + j]) + sh[o.du + (2 * LROWS + r) * LATENT + j]) + dz1 + ckl * mu;
+      v2 = dz2 + ckl * mu2;
+    } else {
+      float t = 0.f;
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {
+        const int q = (pass * LROWS + r) * LATENT + j;
+        t += sh[o.du + q] * 0.5f * sh[o.eps + q] * sh[o.sdv + q];
+      }
+      v = t + dz1 * 0.5f * pre_noise(a, 0, e, rc, j, 16) * expf(0.5f * lv) + ckl * (-0.5f) * (1.f - expf(lv));
+      v2 = dz2 * 0.5f * pre_noise(a, 1, e, rc, j, 16) * expf(0.5f * lv2) + ckl * (-0.5f) * (1.f - expf(lv2));
+    }
+    if (row0 + r < b) {
+      a.dz3enc[((long long)e * 2 * b + row0 + r) * 32 + c] = v;
+      a.dz3enc[((long long)e * 2 * b + b + row0 + r) * 32 + c] = v2;         // s' row: only z2 and its KL term carry a gradient
     }
   }
-  // weight-gradient partials of this workgroup (rows of dead lanes carry zero gradients)
+  // H: weight-gradient partials of this workgroup (rows past the batch carry zero gradients)
   float* zp = a.zap + ((long long)blockIdx.x * NENS + e) * a.za_mf;
-  for (int o = threadIdx.x; o < (int)a.za_mf; o += blockDim.x) {
+  for (int q = tid; q < (int)a.za_mf; q += 256) {
     float s = 0.f;
-    if (o >= a.za_w1 && o < a.za_w1 + za_in * ZH) {
-      const int k = (o - (int)a.za_w1) / ZH, n = (o - (int)a.za_w1) % ZH;
-      for (int i = 0; i < 96; ++i) s += U[i * za_in + k] * DP[i * ZH + n];
-    } else if (o >= a.za_b1 && o < a.za_b1 + ZH) {
-      const int n = o - (int)a.za_b1;
-      for (int i = 0; i < 96; ++i) s += DP[i * ZH + n];
-    } else if (o >= a.za_w2 && o < a.za_w2 + ZH * LATENT) {
-      const int n = (o - (int)a.za_w2) / LATENT, j = (o - (int)a.za_w2) % LATENT;
-      for (int i = 0; i < 96; ++i) s += Hh[i * ZH + n] * DO[i * LATENT + j];
-    } else if (o >= a.za_b2 && o < a.za_b2 + LATENT) {
-      const int j = o - (int)a.za_b2;
-      for (int i = 0; i < 96; ++i) s += DO[i * LATENT + j];
+    if (q >= a.za_w1 && q < a.za_w1 + za_in * ZH) {
+      const int k = (q - (int)a.za_w1) / ZH, n = (q - (int)a.za_w1) % ZH;
+      if (k < LATENT) { for (int p = 0; p < LP; ++p) s += sh[o.z + p * LATENT + k] * sh[o.dpre + p * ZH + n]; }
+      else { for (int p = 0; p < LP; ++p) s += sh[o.act + (p % LROWS) * a.A + (k - LATENT)] * sh[o.dpre + p * ZH + n]; }
+    } else if (q >= a.za_b1 && q < a.za_b1 + ZH) {
+      for (int p = 0; p < LP; ++p) s += sh[o.dpre + p * ZH + (q - (int)a.za_b1)];
+    } else if (q >= a.za_w2 && q < a.za_w2 + ZH * LATENT) {
+      const int n = (q - (int)a.za_w2) / LATENT, j = (q - (int)a.za_w2) % LATENT;
+      for (int p = 0; p < LP; ++p) s += sh[o.hh + p * ZH + n] * sh[o.dout + p * LATENT + j];
+    } else if (q >= a.za_b2 && q < a.za_b2 + LATENT) {
+      for (int p = 0; p < LP; ++p) s += sh[o.dout + p * LATENT + (q - (int)a.za_b2)];
     }
-    zp[o] = s;
+    zp[q] = s;
   }
 }
 
 // action-encoder gradient: sum of the workgroup partials in chunk order (deterministic)
-__global__ __launch_bounds__(256) void k_pre_za_reduce(const float* zap, int nch, long long n, float* grad) {
+__device__ __forceinline__ void za_adam_element(const AdamTarget& a, long long j, float g, const float* sm2) {
+  AdamConsts c = a.c;
+  if (a.t_dev != nullptr) { c.step_size = sm2[0]; c.bc2_sqrt = sm2[1]; }      // adam_block_consts (train.h)
+  const float gj = g * c.gscale;
+  const float m0 = a.m[j];
+  const float mj = m0 + c.w1 * (gj - m0);
+  const float vj = c.b2 * a.v[j] + c.w2 * (gj * gj);
+  a.m[j] = mj; a.v[j] = vj;
+  a.p[j] = a.p[j] - c.step_size * (mj / (sqrtf(vj) / c.bc2_sqrt + c.eps));
+}
+
+__global__ __launch_bounds__(256) void k_pre_za_reduce(const float* zap, int nch, long long n, float* grad, AdamTarget adam) {
+  __shared__ float adam_sm[2];
+  adam_block_consts(adam, adam_sm);
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
-  for (int c = 0; c < nch; ++c) s += zap[(long long)c * n + i];
-  grad[i] = s;
+  int c = 0;
+  for (; c + 4 <= nch; c += 4) {                    // four independent loads in flight, summed in chunk order
+    const float* p = zap + (long long)c * n + i;
+    const float v0 = p[0], v1 = p[n], v2 = p[2 * n], v3 = p[3 * n];
+    s += v0; s += v1; s += v2; s += v3;
+  }
+  for (; c < nch; ++c) s += zap[(long long)c * n + i];
+  if (grad != nullptr) grad[i] = s;
+  if (adam.on) za_adam_element(adam, i, s, adam_sm);       // single-GPU form: the reduction applies the optimizer step itself
 }
 
 // out[5] = (loss, transition_loss, encoder_loss, recon_loss, kl_loss) as learn() reports them (:630-650); local shares
@@ -486,29 +497,27 @@ __global__ __launch_bounds__(256) void k_pre_loss_final(const float* lossp, PreL
 // Adam on the two action encoders' region of the blob (the net that had no gradient this step is skipped, as
 // torch.optim.Adam skips parameters whose .grad is None)
 __global__ __launch_bounds__(256) void k_pre_za_adam(AdamTarget a, const float* g, long long n) {
+  __shared__ float adam_sm[2];
+  adam_block_consts(a, adam_sm);
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  AdamConsts c = a.c;
-  const float gj = g[j] * c.gscale;
-  const float m0 = a.m[j];
-  const float mj = m0 + c.w1 * (gj - m0);
-  const float vj = c.b2 * a.v[j] + c.w2 * (gj * gj);
-  a.m[j] = mj; a.v[j] = vj;
-  a.p[j] = a.p[j] - c.step_size * (mj / (sqrtf(vj) / c.bc2_sqrt + c.eps));
+  za_adam_element(a, j, g[j], adam_sm);
 }
 
 // bootstrap gather of one batch: member e takes dataset rows idx[e][start + r]   (mobody_dynamics.py:604-612, the
 // reference slices pre-gathered [7, n, .] CPU arrays and copies them to the device every batch)
 __global__ __launch_bounds__(256) void k_pre_gather(const float* state, const float* action, const float* next_state,
                                                     const float* reward, const int32_t* idx, long long n_idx, long long start,
-                                                    long long b, int S, int A, float* xenc, float* act, float* rew) {
+                                                    const long long* start_dev, long long b, int S, int A, float* xenc, float* act,
+                                                    float* rew) {
+  if (start_dev != nullptr) start += start_dev[0] * b;      // the device word counts batches
   const int W = 2 * S + A + 1;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long long)NENS * b * W) return;
   const long long er = gid / W;
   const int c = (int)(gid - er * W);
   const long long e = er / b, r = er - e * b;
-  const long long src = idx[e * n_idx + start + r];
+  const long long src = idx[e * n_idx + min(start + r, n_idx - 1)];     // (clamped: a replayed graph can never read past the matrix)
   if (c < S) xenc[(e * 2 * b + r) * S + c] = state[src * S + c];
   else if (c < 2 * S) xenc[(e * 2 * b + b + r) * S + (c - S)] = next_state[src * S + (c - S)];
   else if (c < 2 * S + A) act[er * A + (c - 2 * S)] = action[src * A + (c - 2 * S)];
@@ -569,7 +578,7 @@ static int pre_carve(const MobodyPretrainLayout& L, long long b, float* base, Pr
   long long tf = L.enc.total_floats > L.tr.total_floats ? L.enc.total_floats : L.tr.total_floats;
   if (L.rw.total_floats > tf) tf = L.rw.total_floats;
   w.slabs = take(((tf + 3) & ~3LL) * (w.nsplit4 > w.nsplit2 ? w.nsplit4 : w.nsplit2));
-  w.nch = (int)cdiv(b, 32);
+  w.nch = (int)cdiv(b, LROWS);
   w.zap = take((long long)w.nch * E * L.za_member_floats);
   w.lo.n_lat = (int)(E * w.nch); w.lo.n_rt = (int)cdiv(b * S, 256); w.lo.n_rw = (int)cdiv(E * R2, 256);
   w.lo.lat = 0; w.lo.rt = 2LL * w.lo.n_lat; w.lo.rw = w.lo.rt + 2LL * w.lo.n_rt;
@@ -597,10 +606,6 @@ static Mlp3BwdArgs pre_bwd_args(const MobodyMlpLayout& L, const float* blob_T, c
   b.w3t = L.w3t; b.w2t = L.w2t; b.w1t = L.w1t; b.Np3 = L.Np3; b.Np1t = L.Np1t; b.rows = rows;
   b.dz2 = dz2; b.dz1 = dz1; b.dbp = dbp;
   return b;
-}
-
-static size_t latent_bwd_lds(const MobodyPretrainLayout& L) {
-  return sizeof(float) * (size_t)(((L.za_member_floats + 3) & ~3LL) + 96 * (L.za_in + 2 * ZH + LATENT) + 4 * 32 * 32);
 }
 
 }  // namespace mobody
@@ -657,27 +662,57 @@ extern "C" int64_t mobody_pretrain_workspace(int S, int A, int64_t b) {
 }
 
 extern "C" int mobody_pretrain_gather(const float* state, const float* action, const float* next_state, const float* reward,
-                                      const int32_t* idx, int64_t n_idx, int64_t start, int64_t b, int S, int A, float* xenc,
-                                      float* act, float* rew, void* stream) {
-  MB_REQUIRE(b >= 1 && n_idx >= 1 && start >= 0 && start + b <= n_idx, "mobody_pretrain_gather: rows [%lld, %lld) outside the %lld indices per member",
-             (long long)start, (long long)(start + b), (long long)n_idx);
+                                      const int32_t* idx, int64_t n_idx, int64_t start, const int64_t* start_dev, int64_t b,
+                                      int S, int A, float* xenc, float* act, float* rew, void* stream) {
+  MB_REQUIRE(b >= 1 && n_idx >= 1 && start >= 0 && (start_dev != nullptr || start + b <= n_idx),
+             "mobody_pretrain_gather: rows [%lld, %lld) outside the %lld indices per member", (long long)start,
+             (long long)(start + b), (long long)n_idx);
   MB_REQUIRE(state && action && next_state && reward && idx && xenc && act && rew, "mobody_pretrain_gather: null pointer");
   const long long n = (long long)NENS * b * (2 * S + A + 1);
   hipLaunchKernelGGL(k_pre_gather, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, as_stream(stream), state, action, next_state, reward,
-                     idx, (long long)n_idx, (long long)start, (long long)b, S, A, xenc, act, rew);
+                     idx, (long long)n_idx, (long long)start, (const long long*)start_dev, (long long)b, S, A, xenc, act, rew);
   MB_LAUNCH_OK("k_pre_gather");
   return 0;
 }
 
-extern "C" int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, int use_trg, float encoder_loss_coef,
-                                     const float* blob, const float* blob_T, const float* xenc, const float* act,
-                                     const float* rew, const float* noise6, const float* noise7, uint32_t seed, uint32_t call,
-                                     float* grad, float* loss_out, float* workspace, void* stream) {
+namespace mobody {
+// torch.optim.Adam scalar bookkeeping in double (same forms as train.hip's adam_target); t_dev: device step count
+static AdamTarget pre_adam_target(float* p, float* pT, float* m, float* v, int64_t t, const int64_t* t_dev, float lr,
+                                  float grad_scale) {
+  const double tt = t_dev ? 1.0 : (double)t;
+  const double bc1 = 1.0 - pow(0.9, tt), bc2 = 1.0 - pow(0.999, tt);
+  AdamTarget a{};
+  a.p = p; a.m = m; a.v = v; a.blob_T = pT; a.target = nullptr;
+  a.c.w1 = (float)(1.0 - 0.9); a.c.b2 = (float)0.999; a.c.w2 = (float)(1.0 - 0.999);
+  a.c.step_size = (float)((double)lr / bc1); a.c.bc2_sqrt = (float)sqrt(bc2); a.c.eps = 1e-8f;
+  a.c.tau = -1.f; a.c.one_minus_tau = 0.f; a.c.gscale = grad_scale;
+  a.t_dev = (const long long*)t_dev; a.lr = lr; a.on = 1;
+  return a;
+}
+struct PreOpt {             // fused optimizer step (single GPU): Adam state and step counts; on = 0 -> gradients only
+  int on;
+  float *blob, *blob_T, *m, *v;
+  int64_t t_main, t_za;
+  const int64_t* t_dev;     // device {t_main, t_za} (graph replay) or null
+  float lr;
+};
+}  // namespace mobody
+
+static int pretrain_impl(int S, int A, int64_t b, int64_t b_global, int use_trg, float encoder_loss_coef,
+                         const float* blob, const float* blob_T, const float* xenc, const float* act,
+                         const float* rew, const float* noise6, const float* noise7, uint32_t seed, uint32_t call,
+                         const int64_t* call_dev, float* grad, const PreOpt& opt, float* loss_out, float* workspace,
+                         void* stream) {
   MobodyPretrainLayout L;
   int rc = mobody_pretrain_layout(S, A, &L);
   if (rc) return rc;
-  MB_REQUIRE(b >= 1 && b_global >= b, "mobody_pretrain_grads: need 1 <= b <= b_global");
-  MB_REQUIRE(blob && blob_T && xenc && act && rew && grad && loss_out && workspace, "mobody_pretrain_grads: null pointer");
+  MB_REQUIRE(b >= 1 && b_global >= b, "mobody_pretrain: need 1 <= b <= b_global");
+  MB_REQUIRE(blob && blob_T && xenc && act && rew && (grad || opt.on) && loss_out && workspace, "mobody_pretrain: null pointer");
+  auto region_adam = [&](int64_t off, int64_t toff) {
+    if (!opt.on) return AdamTarget{};
+    return pre_adam_target(opt.blob + off, opt.blob_T + toff, opt.m + off, opt.v + off, opt.t_main, opt.t_dev, opt.lr, 1.f);
+  };
+  auto gptr = [&](int64_t off) { return grad ? grad + off : nullptr; };
   PreWs w;
   pre_carve(L, b, workspace, w);
   hipStream_t st = as_stream(stream);
@@ -687,7 +722,6 @@ extern "C" int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, 
     rc = allow_big_lds(k_mlp3_fwd_train<0>, 160 * 1024);
     if (!rc) rc = allow_big_lds(k_mlp3_fwd_train<1>, 160 * 1024);
     if (!rc) rc = allow_big_lds(k_mlp3_fwd_train<2>, 160 * 1024);
-    if (!rc) rc = allow_big_lds(k_pre_latent_bwd, 160 * 1024);
     if (rc) return rc;
     once = true;
   }
@@ -695,6 +729,7 @@ extern "C" int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, 
   r.S = S; r.A = A; r.use_trg = use_trg; r.Np3tr = L.tr.Np3; r.b = b; r.inv_bg = 1.f / (float)b_global;
   r.ce = (use_trg ? 5.f : 1.f) * encoder_loss_coef; r.cr = use_trg ? 1.f : 0.01f;
   r.xenc = xenc; r.act = act; r.rew = rew; r.noise6 = noise6; r.noise7 = noise7; r.seed = seed; r.call = call;
+  r.call_dev = (const long long*)call_dev;
   r.za = blob + (use_trg ? L.off_za_trg : L.off_za_src);
   r.za_mf = L.za_member_floats; r.za_w1 = L.za_w1; r.za_b1 = L.za_b1; r.za_w2 = L.za_w2; r.za_b2 = L.za_b2;
   r.enc_out = w.enc_out; r.zt = w.zt; r.tr_out = w.tr_out; r.dz3tr = w.dz3tr; r.xrw = w.xrw; r.rw_out = w.rw_out;
@@ -705,7 +740,8 @@ extern "C" int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, 
   // ---- forward ----
   rc = launch_fwd_train(pre_fwd_args(Penc, L.enc, xenc, S, R2, w.enc_out, w.sx_enc, w.h1e, w.h2e, w.d1e, w.d2e), NENS, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_pre_latent_fwd, dim3((unsigned)w.nch, NENS), dim3(128), sizeof(float) * (size_t)L.za_member_floats, st, r, w.lo);
+  const LatentLds ll = latent_lds(L.za_member_floats, A);
+  hipLaunchKernelGGL(k_pre_latent_fwd, dim3((unsigned)w.nch, NENS), dim3(256), sizeof(float) * (size_t)ll.total, st, r, w.lo, ll);
   MB_LAUNCH_OK("k_pre_latent_fwd");
   rc = launch_fwd_train(pre_fwd_args(Ptr, L.tr, w.zt, LATENT, R4, w.tr_out, nullptr, w.h1t, w.h2t, w.d1t, w.d2t), NENS, st);
   if (rc) return rc;
@@ -722,7 +758,7 @@ extern "C" int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, 
     rc = launch_mlp3_bwd(bw, NENS, true, 32, st);
     if (rc) return rc;
     rc = mlp3_weight_grads(L.rw, w.sx_rw, R2 * L.rw.Kp1, w.h1r, w.h2r, w.dz3rw, w.dz2, w.dz1, R2, w.nsplit2, w.slabs, w.dbp,
-                           w.ntiles2, grad + L.off_rw, LossFinal{}, AdamTarget{}, st);
+                           w.ntiles2, gptr(L.off_rw), LossFinal{}, region_adam(L.off_rw, L.t_off_rw), st);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(k_pre_fake_bwd, dim3((unsigned)cdiv(b * S, 256)), dim3(256), 0, st, r);
@@ -734,16 +770,18 @@ extern "C" int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, 
     rc = launch_mlp3_bwd(bw, NENS, true, 32, st);
     if (rc) return rc;
     rc = mlp3_weight_grads(L.tr, w.zt, R4 * LATENT, w.h1t, w.h2t, w.dz3tr, w.dz2, w.dz1, R4, w.nsplit4, w.slabs, w.dbp,
-                           w.ntiles4, grad + L.off_tr, LossFinal{}, AdamTarget{}, st);
+                           w.ntiles4, gptr(L.off_tr), LossFinal{}, region_adam(L.off_tr, L.t_off_tr), st);
     if (rc) return rc;
   }
   // ---- latent level + action encoder ----
-  hipLaunchKernelGGL(k_pre_latent_bwd, dim3((unsigned)w.nch, NENS), dim3(128), latent_bwd_lds(L), st, r, (int)L.za_in);
+  hipLaunchKernelGGL(k_pre_latent_bwd, dim3((unsigned)w.nch, NENS), dim3(256), sizeof(float) * (size_t)ll.total, st, r, ll, (int)L.za_in);
   MB_LAUNCH_OK("k_pre_latent_bwd");
   {
     const long long n = (long long)NENS * L.za_member_floats;
-    hipLaunchKernelGGL(k_pre_za_reduce, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.zap, w.nch, n,
-                       grad + (use_trg ? L.off_za_trg : L.off_za_src));
+    const int64_t oz = use_trg ? L.off_za_trg : L.off_za_src;
+    AdamTarget za{};
+    if (opt.on) za = pre_adam_target(opt.blob + oz, nullptr, opt.m + oz, opt.v + oz, opt.t_za, opt.t_dev ? opt.t_dev + 1 : nullptr, opt.lr, 1.f);
+    hipLaunchKernelGGL(k_pre_za_reduce, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.zap, w.nch, n, gptr(oz), za);
     MB_LAUNCH_OK("k_pre_za_reduce");
   }
   // ---- state encoder ----
@@ -752,7 +790,7 @@ extern "C" int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, 
     rc = launch_mlp3_bwd(bw, NENS, false, 32, st);
     if (rc) return rc;
     rc = mlp3_weight_grads(L.enc, w.sx_enc, R2 * L.enc.Kp1, w.h1e, w.h2e, w.dz3enc, w.dz2, w.dz1, R2, w.nsplit2, w.slabs, w.dbp,
-                           w.ntiles2, grad + L.off_enc, LossFinal{}, AdamTarget{}, st);
+                           w.ntiles2, gptr(L.off_enc), LossFinal{}, region_adam(L.off_enc, L.t_off_enc), st);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(k_pre_loss_final, dim3(1), dim3(256), 0, st, w.lossp, w.lo, r.inv_bg, S, r.ce, r.cr, loss_out);
@@ -760,19 +798,26 @@ extern "C" int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, 
   return 0;
 }
 
-namespace mobody {
-// torch.optim.Adam scalar bookkeeping in double (same forms as train.hip's adam_target)
-static AdamTarget pre_adam_target(float* p, float* pT, float* m, float* v, int64_t t, float lr, float grad_scale) {
-  const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
-  AdamTarget a{};
-  a.p = p; a.m = m; a.v = v; a.blob_T = pT; a.target = nullptr;
-  a.c.w1 = (float)(1.0 - 0.9); a.c.b2 = (float)0.999; a.c.w2 = (float)(1.0 - 0.999);
-  a.c.step_size = (float)((double)lr / bc1); a.c.bc2_sqrt = (float)sqrt(bc2); a.c.eps = 1e-8f;
-  a.c.tau = -1.f; a.c.one_minus_tau = 0.f; a.c.gscale = grad_scale;
-  a.t_dev = nullptr; a.lr = lr; a.on = 1;
-  return a;
+extern "C" int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, int use_trg, float encoder_loss_coef,
+                                     const float* blob, const float* blob_T, const float* xenc, const float* act,
+                                     const float* rew, const float* noise6, const float* noise7, uint32_t seed, uint32_t call,
+                                     float* grad, float* loss_out, float* workspace, void* stream) {
+  MB_REQUIRE(grad, "mobody_pretrain_grads: grad is null");
+  return pretrain_impl(S, A, b, b_global, use_trg, encoder_loss_coef, blob, blob_T, xenc, act, rew, noise6, noise7, seed, call,
+                       nullptr, grad, PreOpt{}, loss_out, workspace, stream);
 }
-}  // namespace mobody
+
+extern "C" int mobody_pretrain_update(int S, int A, int64_t b, int use_trg, float encoder_loss_coef, float* blob, float* blob_T,
+                                      const float* xenc, const float* act, const float* rew, const float* noise6,
+                                      const float* noise7, uint32_t seed, uint32_t call, const int64_t* call_dev, float* m,
+                                      float* v, int64_t t_main, int64_t t_za, const int64_t* t_dev, float lr, float* loss_out,
+                                      float* workspace, void* stream) {
+  MB_REQUIRE(m && v, "mobody_pretrain_update: null pointer");
+  MB_REQUIRE(t_dev != nullptr || (t_main >= 1 && t_za >= 1), "mobody_pretrain_update: step counts are 1-based");
+  PreOpt o{1, blob, blob_T, m, v, t_main, t_za, t_dev, lr};
+  return pretrain_impl(S, A, b, b, use_trg, encoder_loss_coef, blob, blob_T, xenc, act, rew, noise6, noise7, seed, call, call_dev,
+                       nullptr, o, loss_out, workspace, stream);
+}
 
 extern "C" int mobody_pretrain_adam(int S, int A, int use_trg, float* blob, float* blob_T, const float* grad, float* m,
                                     float* v, int64_t t_main, int64_t t_za, float lr, float grad_scale, void* stream) {
@@ -785,13 +830,13 @@ extern "C" int mobody_pretrain_adam(int S, int A, int use_trg, float* blob, floa
   const MobodyMlpLayout* nets[3] = {&L.enc, &L.tr, &L.rw};
   const int64_t offs[3] = {L.off_enc, L.off_tr, L.off_rw}, toffs[3] = {L.t_off_enc, L.t_off_tr, L.t_off_rw};
   for (int k = 0; k < 3; ++k) {
-    const AdamTarget a = pre_adam_target(blob + offs[k], blob_T + toffs[k], m + offs[k], v + offs[k], t_main, lr, grad_scale);
+    const AdamTarget a = pre_adam_target(blob + offs[k], blob_T + toffs[k], m + offs[k], v + offs[k], t_main, nullptr, lr, grad_scale);
     rc = launch_adam(a, grad + offs[k], *nets[k], st);
     if (rc) return rc;
   }
   const int64_t oz = use_trg ? L.off_za_trg : L.off_za_src;
   const long long nz = (long long)NENS * L.za_member_floats;
-  const AdamTarget a = pre_adam_target(blob + oz, nullptr, m + oz, v + oz, t_za, lr, grad_scale);
+  const AdamTarget a = pre_adam_target(blob + oz, nullptr, m + oz, v + oz, t_za, nullptr, lr, grad_scale);
   hipLaunchKernelGGL(k_pre_za_adam, dim3((unsigned)cdiv(nz, 256)), dim3(256), 0, st, a, grad + oz, nz);
   MB_LAUNCH_OK("k_pre_za_adam");
   return 0;

@@ -146,9 +146,11 @@ __global__ __launch_bounds__(256) void k_sum_scale(const float* parts, int n, fl
 // Adam + Polyak, transposes
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_adam(AdamTarget a, const float* g, long long n, MobodyMlpLayout L) {
+  __shared__ float adam_sm[2];
+  adam_block_consts(a, adam_sm);
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
-  adam_element(a, L, j, g[j]);
+  adam_element(a, L, j, g[j], adam_sm);
 }
 
 int launch_adam(const AdamTarget& a, const float* g, const MobodyMlpLayout& L, hipStream_t st) {

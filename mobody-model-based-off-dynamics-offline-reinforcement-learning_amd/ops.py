@@ -329,7 +329,7 @@ def pretrain_workspace(S, A, b, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
-def pretrain_gather(state, action, next_state, reward, idx, start, b, out=None):
+def pretrain_gather(state, action, next_state, reward, idx, start, b, out=None, start_dev=None):
     """idx: device int32 [7, n_idx].  Returns (xenc[7,2b,S], act[7,b,A], rew[7,b])."""
     S, A = state.shape[1], action.shape[1]
     dev = state.device
@@ -338,7 +338,8 @@ def pretrain_gather(state, action, next_state, reward, idx, start, b, out=None):
                              torch.empty(7, b, A, dtype=torch.float32, device=dev),
                              torch.empty(7, b, dtype=torch.float32, device=dev))
     check(load().mobody_pretrain_gather(ptr(state), ptr(action), ptr(next_state), ptr(reward), ptr(idx), idx.shape[1], start,
-                                        b, S, A, ptr(xenc), ptr(act), ptr(rew), cur_stream()), "mobody_pretrain_gather")
+                                        ptr(start_dev), b, S, A, ptr(xenc), ptr(act), ptr(rew), cur_stream()),
+          "mobody_pretrain_gather")
     return xenc, act, rew
 
 
@@ -348,6 +349,14 @@ def pretrain_grads(S, A, b, use_trg, encoder_loss_coef, blob, blob_T, xenc, act,
                                        float(encoder_loss_coef), ptr(blob), ptr(blob_T), ptr(xenc), ptr(act), ptr(rew),
                                        ptr(noise6), ptr(noise7), seed, call, ptr(grad), ptr(loss_out), ptr(ws),
                                        cur_stream()), "mobody_pretrain_grads")
+
+
+def pretrain_update(S, A, b, use_trg, encoder_loss_coef, blob, blob_T, xenc, act, rew, m, v, t_main, t_za, lr, loss_out, ws,
+                    noise6=None, noise7=None, seed=0, call=0, call_dev=None, t_dev=None):
+    check(load().mobody_pretrain_update(S, A, b, int(bool(use_trg)), float(encoder_loss_coef), ptr(blob), ptr(blob_T), ptr(xenc),
+                                        ptr(act), ptr(rew), ptr(noise6), ptr(noise7), seed, call, ptr(call_dev), ptr(m), ptr(v),
+                                        t_main, t_za, ptr(t_dev), float(lr), ptr(loss_out), ptr(ws), cur_stream()),
+          "mobody_pretrain_update")
 
 
 def pretrain_adam(S, A, use_trg, blob, blob_T, grad, m, v, t_main, t_za, lr, grad_scale=1.0):

@@ -293,3 +293,44 @@ def _retarget(tr, b):
     tr.b = b
     tr.ws = tr.ops.pretrain_workspace(tr.S, tr.A, b, tr.dev)
     return tr
+
+
+def test_pretrain_graph_replay_equals_eager_fused_steps(dev):
+    """One pass of _learn_indexed (5 full batches + a ragged one, device-Philox noise): the captured-graph replay (batch
+    offset, noise call id and Adam step counts advanced in device words) equals the eager fused steps; the only
+    difference allowed is the device-side double pow of the Adam bias corrections (1 ulp of fp32), and both equal the
+    unfused grads + Adam entry points."""
+    S, A, b = 17, 6, 32
+    p = gu.gi.dyn_params(5, S, A)
+    n = 400
+    s, a, s2, r, _ = gu.gi.batch(4, n, S, A)
+    td = lambda x: torch.from_numpy(x).to(dev)
+    data = [td(s), td(a), td(s2), td(r)]
+    idx = td(np.random.default_rng(2).integers(0, n, (7, 5 * b + 7)).astype(np.int32)).contiguous()
+    out = {}
+    for mode in ("graph", "eager"):
+        dyn, m = _mirror_dynamics(p, S, A, dev, dict(train_graph=int(mode == "graph")))
+        dyn.seed = 9
+        st1 = dyn._learn_indexed(True, data, idx, b)
+        st2 = dyn._learn_indexed(False, data, idx, b)
+        assert (len(dyn._pre_graphs) == 2) == (mode == "graph")
+        assert dyn.model.train_state()["t_main"] == 12 and dyn.model.train_state()["t_za"] == {False: 6, True: 6}
+        out[mode] = (st1, st2, {k: v.cpu() for k, v in m.state_dict().items() if k in p})   # (saved_* / decoders: random init)
+    for k in out["graph"][2]:
+        np.testing.assert_allclose(out["graph"][2][k].numpy(), out["eager"][2][k].numpy(), rtol=2e-6, atol=1e-8, err_msg=k)
+    close(np.array(out["graph"][0]), np.array(out["eager"][0]), rtol=1e-5, atol=1e-6)
+    close(np.array(out["graph"][1]), np.array(out["eager"][1]), rtol=1e-5, atol=1e-6)
+    # unfused entry points (what data-parallel ranks use) fed with the same Philox streams
+    tr = Trainer(p, S, A, b, dev)
+    sel = idx.cpu().numpy()[:, :b]
+    nz = [O.rng_normal(9 + 77, 16 + k, 1, 7 * b * 16).reshape(7, b, 16) for k in range(6)] + [O.rng_normal(9 + 77, 22, 1, 7 * b * S).reshape(7, b, S)]
+    tr.grads((s[sel], a[sel], s2[sel], r[sel]), nz, True)
+    tr.apply(True)
+    dyn, m = _mirror_dynamics(p, S, A, dev, dict(train_graph=0))
+    dyn.seed = 9
+    dyn._learn_indexed(True, data, idx[:, :b].contiguous(), b)
+    full2 = {k: torch.from_numpy(p[k]).to(dev) for k in ("za_src2.weight", "za_trg2.weight", "za_src2.bias", "za_trg2.bias")}
+    got = m.state_dict()
+    for k, v in tr.unpack(tr.blob, full2).items():
+        # (the CPU twin of the Philox normals agrees with the device to ~2e-6, and Adam's first step is sign-like)
+        np.testing.assert_allclose(got[k].cpu().numpy(), v.cpu().numpy(), rtol=2e-5, atol=5e-6, err_msg=k)
