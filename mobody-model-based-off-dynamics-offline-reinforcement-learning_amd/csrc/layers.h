@@ -131,8 +131,6 @@ struct Mlp3FwdArgs {
 };
 
 int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stream);
-int launch_mlp3_fwd16(const Mlp3FwdArgs& a, int members, int mt, hipStream_t stream);   // mlp_fwd16.hip (Np3 16 or 32)
-int pick_mt16(long long row_members);
 int launch_mlp3_fwd_pair(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, hipStream_t stream);
 
 // Row-tile height of the fused MLP kernels.  Measured on MI355X (bench.py, S=17/A=6): 32-row tiles (33 KB LDS,

@@ -183,9 +183,6 @@ static int launch_fwd_act(const Mlp3FwdArgs& a, int members, hipStream_t stream)
 
 int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stream) {
   if (a.rows <= 0) return 0;
-  static const bool core16 = [] { const char* e = getenv("MOBODY_CORE16"); return e && atoi(e) != 0; }();
-  if (core16 && act == ACT_RELU && (a.Np3 == 16 || a.Np3 == 32) && a.mask1 == nullptr && a.mask2 == nullptr)
-    return launch_mlp3_fwd16(a, members, pick_mt16(a.rows * members), stream);
   return act == ACT_SWISH ? launch_fwd_act<ACT_SWISH>(a, members, stream) : launch_fwd_act<ACT_RELU>(a, members, stream);
 }
 
