@@ -8,6 +8,7 @@
  *   mobody_dyn_step      <- MOBODYEnsembleDynamics.step           algo/dynamics/mobody_dynamics.py:193-265
  *                           (+ termination predicates             algo/mb_utils/terminal_funs.py:10-149)
  *   mobody_mlp3_forward  <- Policy / DoubleQFunc / ValueFunc fwd  algo/offline_offline/mobody.py:35-83
+ *   mobody_rollout       <- MOBODY.rollout + add_batch            algo/offline_offline/mobody.py:596-657, algo/utils.py:43-92
  *   mobody_gather_batch  <- ReplayBuffer.sample x3 + torch.cat    algo/utils.py:127-148, mobody.py:399-400,516-529
  *   mobody_ring_append   <- ReplayBuffer.add_batch (+ filter)     algo/utils.py:43-92, mobody.py:468,648-653
  *   mobody_critic_step   <- update_q_functions + backward         mobody.py:189-208,544-547
@@ -127,6 +128,21 @@ int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, const float* 
                     uint8_t* terminal, float* penalty, float* raw_reward, float* mean_out, float* workspace,
                     void* stream);
 
+/* The whole H-step imagined rollout on the device, appended to a ring buffer (MOBODY.rollout + add_batch,
+ * mobody.py:596-657, utils.py:43-92): per step a = pi(s) (actor blob, mobody_mlp_layout(S, A, 1)), one fused ensemble
+ * step with device-Philox noise / elite picks at call id call0 + t, the penalty filter (`penalty <= env_filter` when
+ * filter_bad_rollout) and the alive update formed in the sample kernel, and a two-launch stream-compacting append of the
+ * kept rows: 7 launches per step, no host work and no synchronisation between steps.  Rows keep their index across
+ * steps; a row that terminated is computed but never appended again (the reference drops it from the batch, :635-639).
+ * NB quirk Q1: MOBODY.rollout passes its `use_trg` argument in step()'s `use_penalty` slot -- callers mirror that here.
+ * workspace: mobody_rollout_workspace(S, A, B) floats. */
+int64_t mobody_rollout_workspace(int S, int A, int64_t B);
+int mobody_rollout(const float* dyn_blob, const float* actor_blob, int S, int A, int task, float max_action,
+                   const float* init_obs, int64_t B, int H, const int32_t* elites, int n_elites, uint32_t seed, uint32_t call0,
+                   float penalty_coef, int use_penalty, int use_trg, float env_filter, int filter_bad_rollout, float* b_state,
+                   float* b_action, float* b_next_state, float* b_reward, float* b_not_done, int64_t cap, int64_t* ptr_size,
+                   float* workspace, void* stream);
+
 /* Termination predicate alone: done[B] (uint8) = terminal_fn(next_obs[B][S])  (terminal_funs.py:10-121). */
 int mobody_termination(int task, const float* next_obs, int64_t B, int S, uint8_t* done, void* stream);
 
@@ -178,7 +194,8 @@ int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64_t* counts,
 
 /* Append the rows with keep[i] != 0 (NULL = all), in order, to a ring buffer of `cap` rows at
  * *ptr_size (device int64[2] = {ptr, size}), reproducing add_batch's single-wrap arithmetic
- * (utils.py:43-92); not_done = 1 - terminal.  `scan_ws` needs (M + 1024) int32. */
+ * (utils.py:43-92); not_done = 1 - terminal.  `scan_ws` needs (M + 1040) int32.  Two launches: a block scan whose last
+ * block commits the new {ptr, size}, and the row scatter. */
 int mobody_ring_append(float* b_state, float* b_action, float* b_next_state, float* b_reward, float* b_not_done,
                        int64_t cap, int64_t* ptr_size, int S, int A, const float* obs, const float* act,
                        const float* next_obs, const float* reward, const uint8_t* terminal, const uint8_t* keep,

@@ -347,25 +347,22 @@ class MOBODY(object):
         return res, {"num_transitions": n_tr, "reward_mean": rew_mean}
 
     def _rollout_into_fake(self, init_obss, rollout_length, use_trg=True):
-        """Same transitions as rollout()+add_batch, without host compaction: rows keep their index, an
-        alive mask replaces the shrinking batch and the penalty filter is fused into the ring append."""
+        """Same transitions as rollout()+add_batch, entirely on the device (`mobody_rollout`): rows keep their index, an
+        alive mask replaces the shrinking batch, the penalty filter and the alive update are formed in the sample kernel and
+        the kept rows are stream-compacted into the ring -- 7 launches per horizon step, no host work between steps."""
         if rollout_length == 0:
             return 0
-        obs = init_obss
+        dyn, m, fb = self.dynamics, self.dynamics.model, self.fake_replay_buffer
+        obs = init_obss.contiguous()
         B = obs.shape[0]
-        alive = None
-        keep = torch.empty(B, dtype=torch.uint8, device=self.device)
-        for _ in range(rollout_length):
-            act = self.policy(obs).reshape(-1, self.A)
-            r = self.dynamics.step_device(obs, act, use_trg, alive=alive)
-            nalive = torch.empty(B, dtype=torch.uint8, device=self.device)
-            ops.rollout_mask(alive, r["terminal"], r["penalty"], self.config["env_filter"],
-                             self.config["filter_bad_rollout"], keep, nalive)
-            fb = self.fake_replay_buffer
-            ops.ring_append(fb._fields(), fb.max_size, fb.ptr_size, self.S, self.A, obs, act, r["next_obs"],
-                            r["reward"], r["terminal"], keep)
-            obs, alive = r["next_obs"], nalive
-        self.fake_replay_buffer._pull()
+        m.inference()
+        self._roll_ws = ops.rollout(m.packed(), self.policy.blob, self.S, self.A, dyn._task_id, self.policy.max_action, obs,
+                                    rollout_length, [int(e) for e in m.elites.tolist()],
+                                    (dyn.seed + dp.rank_salt()) & 0xFFFFFFFF, dyn._calls + 1, float(dyn._penalty_coef or 0.0),
+                                    use_trg, True, self.config["env_filter"], self.config["filter_bad_rollout"],   # quirk Q1
+                                    fb._fields(), fb.max_size, fb.ptr_size, getattr(self, "_roll_ws", None))
+        dyn._calls += rollout_length
+        fb._pull()
         return B * rollout_length
 
     def _refresh(self, src_rb, tar_rb, batch_size):

@@ -132,6 +132,11 @@ struct DynSampleArgs {
   float* next_obs;           // [B][S]
   float* penalty;            // [B]
   uint8_t* terminal;         // [B]
+  // multi-step rollout bookkeeping fused in (MOBODY.rollout mobody.py:635-653 without host compaction), both optional:
+  uint8_t* keep;             // [B] alive_in && (!use_filter || penalty <= env_filter)
+  uint8_t* alive_out;        // [B] alive_in && !terminal   (may alias `alive`)
+  float env_filter;
+  int use_filter;
 };
 
 __device__ __forceinline__ bool term_predicate(int task, const float* n, int S) {
@@ -210,8 +215,12 @@ __global__ __launch_bounds__(256) void k_dyn_sample(DynSampleArgs a, int rpb) {
     for (int e = 0; e < NENS; ++e) { const float q = s_sq[tid * NENS + e]; bad = bad || (q != q); pmax = fmaxf(pmax, q); }
     a.penalty[bb] = bad ? __builtin_nanf("") : sqrtf(pmax);                // :246-249 (last state dim dropped)
     bool done = term_predicate(a.task, s_nxt + tid * S, S);
-    if (a.alive && !a.alive[bb]) done = true;
+    const bool was_alive = a.alive ? a.alive[bb] != 0 : true;
+    if (!was_alive) done = true;
     a.terminal[bb] = done ? 1 : 0;
+    const float pen = a.penalty[bb];
+    if (a.keep) a.keep[bb] = (was_alive && (!a.use_filter || pen <= a.env_filter)) ? 1 : 0;     // NaN penalty: dropped (:648-653)
+    if (a.alive_out) a.alive_out[bb] = (was_alive && !done) ? 1 : 0;
   }
 }
 
@@ -282,11 +291,12 @@ extern "C" int64_t mobody_dyn_step_workspace(int S, int A, int64_t B) {
   return (int64_t)NENS * B * S + (int64_t)NENS * B;    // ensemble means + per-member reward means
 }
 
-extern "C" int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, const float* obs, const float* act,
-                               int64_t B, const float* noise, const int32_t* elite_idx, const uint8_t* alive,
-                               const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty,
-                               int use_trg, float* next_obs, float* reward, uint8_t* terminal, float* penalty,
-                               float* raw_reward, float* mean_out, float* workspace, void* stream) {
+static int dyn_step_impl(const float* dyn_blob, int S, int A, int task, const float* obs, const float* act,
+                         int64_t B, const float* noise, const int32_t* elite_idx, const uint8_t* alive,
+                         const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty,
+                         int use_trg, float* next_obs, float* reward, uint8_t* terminal, float* penalty,
+                         float* raw_reward, float* mean_out, float* workspace, uint8_t* keep, uint8_t* alive_out,
+                         float env_filter, int use_filter, void* stream) {
   MobodyDynLayout L;
   int rc = mobody_dyn_layout(S, A, &L);
   if (rc) return rc;
@@ -308,6 +318,7 @@ extern "C" int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, co
   for (int k = 0; k < NENS; ++k) sa.elites[k] = (elites && k < n_elites) ? elites[k] : 0;
   sa.n_elites = n_elites; sa.seed = seed; sa.call = call; sa.B = B; sa.S = S; sa.task = task;
   sa.next_obs = next_obs; sa.penalty = penalty; sa.terminal = terminal;
+  sa.keep = keep; sa.alive_out = alive_out; sa.env_filter = env_filter; sa.use_filter = use_filter;
   const int rpb = 256 / S < 64 ? 256 / S : 64;         // whole rows per workgroup (S <= 256 is checked by the layout)
   hipLaunchKernelGGL(k_dyn_sample, dim3((unsigned)cdiv(B, rpb)), dim3(256), 0, st, sa, rpb);
   MB_LAUNCH_OK("k_dyn_sample");
@@ -330,6 +341,84 @@ extern "C" int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, co
   DynFinalArgs fa{r_mu, penalty, reward, raw_reward, B, (penalty_coef != 0.f && use_penalty) ? penalty_coef : 0.f};
   hipLaunchKernelGGL(k_dyn_finalize, dim3((unsigned)cdiv(B, 256)), dim3(256), 0, st, fa);
   MB_LAUNCH_OK("k_dyn_finalize");
+  return 0;
+}
+
+extern "C" int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, const float* obs, const float* act,
+                               int64_t B, const float* noise, const int32_t* elite_idx, const uint8_t* alive,
+                               const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty,
+                               int use_trg, float* next_obs, float* reward, uint8_t* terminal, float* penalty,
+                               float* raw_reward, float* mean_out, float* workspace, void* stream) {
+  return dyn_step_impl(dyn_blob, S, A, task, obs, act, B, noise, elite_idx, alive, elites, n_elites, seed, call, penalty_coef,
+                       use_penalty, use_trg, next_obs, reward, terminal, penalty, raw_reward, mean_out, workspace, nullptr, nullptr,
+                       0.f, 0, stream);
+}
+
+// ---- whole H-step imagined rollout on the device (MOBODY.rollout + add_batch, mobody.py:596-657, utils.py:43-92) ----
+namespace mobody {
+struct RolloutWs {
+  float *obs[2], *act, *reward, *penalty, *dyn;
+  uint8_t *terminal, *keep, *alive;
+  int32_t* scan;
+  long long total;
+};
+static void rollout_carve(int S, int A, long long B, float* base, RolloutWs& w) {
+  long long off = 0;
+  auto take = [&](long long n) { float* p = base ? base + off : nullptr; off += (n + 3) & ~3LL; return p; };
+  w.obs[0] = take(B * S); w.obs[1] = take(B * S); w.act = take(B * A); w.reward = take(B); w.penalty = take(B);
+  w.dyn = take((long long)NENS * B * S + (long long)NENS * B);
+  w.terminal = (uint8_t*)take((B + 3) / 4); w.keep = (uint8_t*)take((B + 3) / 4); w.alive = (uint8_t*)take((B + 3) / 4);
+  w.scan = (int32_t*)take(B + 1040);
+  w.total = off;
+}
+}  // namespace mobody
+
+extern "C" int64_t mobody_rollout_workspace(int S, int A, int64_t B) {
+  RolloutWs w;
+  rollout_carve(S, A, B, nullptr, w);
+  return w.total;
+}
+
+extern "C" int mobody_rollout(const float* dyn_blob, const float* actor_blob, int S, int A, int task, float max_action,
+                              const float* init_obs, int64_t B, int H, const int32_t* elites, int n_elites, uint32_t seed,
+                              uint32_t call0, float penalty_coef, int use_penalty, int use_trg, float env_filter,
+                              int filter_bad_rollout, float* b_state, float* b_action, float* b_next_state, float* b_reward,
+                              float* b_not_done, int64_t cap, int64_t* ptr_size, float* workspace, void* stream) {
+  MB_REQUIRE(B >= 0 && H >= 0, "mobody_rollout: bad sizes");
+  if (B == 0 || H == 0) return 0;
+  MB_REQUIRE(B <= cap, "mobody_rollout: %lld rows per step overflow the ring of %lld twice", (long long)B, (long long)cap);
+  MB_REQUIRE(dyn_blob && actor_blob && init_obs && elites && b_state && b_action && b_next_state && b_reward && b_not_done &&
+                 ptr_size && workspace, "mobody_rollout: null pointer");
+  MobodyMlpLayout La;
+  int rc = mobody_mlp_layout(S, A, 1, &La);
+  if (rc) return rc;
+  RolloutWs w;
+  rollout_carve(S, A, B, workspace, w);
+  hipStream_t st = as_stream(stream);
+  const float* obs = init_obs;
+  for (int t = 0; t < H; ++t) {
+    float* nxt = w.obs[t & 1];
+    // a = pi(s)  (select_action, mobody.py:612)
+    Mlp3FwdArgs p{};
+    p.src[0] = obs; p.ld[0] = S; p.n[0] = S;
+    p.w1 = actor_blob + La.w1; p.b1 = actor_blob + La.b1; p.w2 = actor_blob + La.w2; p.b2 = actor_blob + La.b2;
+    p.w3 = actor_blob + La.w3; p.b3 = actor_blob + La.b3;
+    p.sw1 = p.sb1 = p.sw2 = p.sb2 = p.sw3 = p.sb3 = La.member_floats;
+    p.Kp1 = La.Kp1; p.Np3 = La.Np3; p.nout = A; p.rows = B; p.out = w.act; p.out_mstride = B * A; p.out_ld = A;
+    p.out_mode = 1; p.max_action = max_action;
+    rc = launch_mlp3_fwd(p, 1, ACT_RELU, st);
+    if (rc) return rc;
+    // one imagined transition for every row; rows that terminated earlier keep their index and are flagged (alive mask);
+    // the penalty filter and the alive update are formed in the sample kernel
+    rc = dyn_step_impl(dyn_blob, S, A, task, obs, w.act, B, nullptr, nullptr, t == 0 ? nullptr : w.alive, elites, n_elites, seed,
+                       call0 + (uint32_t)t, penalty_coef, use_penalty, use_trg, nxt, w.reward, w.terminal, w.penalty, nullptr, nullptr,
+                       w.dyn, w.keep, w.alive, env_filter, filter_bad_rollout, stream);
+    if (rc) return rc;
+    rc = launch_ring_append(b_state, b_action, b_next_state, b_reward, b_not_done, cap, (long long*)ptr_size, S, A, obs, w.act, nxt,
+                            w.reward, w.terminal, w.keep, B, w.scan, st);
+    if (rc) return rc;
+    obs = nxt;
+  }
   return 0;
 }
 

@@ -23,39 +23,63 @@ struct GatherArgs {
   const long long* size[3];
 };
 
+// One ROW per 16-lane group (16 rows per workgroup): the source index -- an explicit index or one Philox draw -- is formed
+// once per row by the group's first lane and broadcast, then the group's lanes copy the five SoA pieces of the row with
+// consecutive addresses.  (The first version ran one thread per FLOAT: an integer division and a full Philox-10 per
+// element, 42 per row at S=17/A=6 -- the kernel was ALU bound at 1.0 TB/s.)
 __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
-  const int W = 2 * a.S + a.A + 2;
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 15;
+  const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
   const long long N = a.start[a.nbuf];
-  if (gid >= N * W) return;
-  const long long row = gid / W;
-  const int c = (int)(gid - row * W);
+  const bool ok = row < N;
+  const long long r = ok ? row : 0;
   int k = 0;
-  if (a.nbuf > 1 && row >= a.start[1]) k = 1;
-  if (a.nbuf > 2 && row >= a.start[2]) k = 2;
-  long long src;
-  if (a.idx[k] != nullptr) {
-    src = a.idx[k][row - a.start[k]];
-  } else {
-    const uint32_t call = (uint32_t)((a.counter ? a.counter[0] : 0) + a.call_offset[k]);
-    const long long sz = a.size[k][0];
-    src = rng_index_at(a.seed[k], STREAM_SAMPLE, call, (uint64_t)(row - a.start[k]), (uint32_t)(sz > 0 ? sz : 1));
+  if (a.nbuf > 1 && r >= a.start[1]) k = 1;
+  if (a.nbuf > 2 && r >= a.start[2]) k = 2;
+  long long src = 0;
+  if (lane == 0) {
+    if (a.idx[k] != nullptr) {
+      src = a.idx[k][r - a.start[k]];
+    } else {
+      const uint32_t call = (uint32_t)((a.counter ? a.counter[0] : 0) + a.call_offset[k]);
+      const long long sz = a.size[k][0];
+      src = rng_index_at(a.seed[k], STREAM_SAMPLE, call, (uint64_t)(r - a.start[k]), (uint32_t)(sz > 0 ? sz : 1));
+    }
   }
+  src = __shfl(src, threadIdx.x & 48, 64);            // lane 0 of this 16-lane group (groups are 16-aligned inside the wave)
+  if (!ok) return;
   const int S = a.S, A = a.A;
-  if (c < S) a.state[row * S + c] = a.bufs[k].state[src * S + c];
-  else if (c < S + A) a.action[row * A + (c - S)] = a.bufs[k].action[src * A + (c - S)];
-  else if (c < 2 * S + A) a.next_state[row * S + (c - S - A)] = a.bufs[k].next_state[src * S + (c - S - A)];
-  else if (c == 2 * S + A) a.reward[row] = a.bufs[k].reward[src];
-  else a.not_done[row] = a.bufs[k].not_done[src];
+  const MobodyBufferView& b = a.bufs[k];
+  for (int c = lane; c < S; c += 16) {
+    a.state[row * S + c] = b.state[src * S + c];
+    a.next_state[row * S + c] = b.next_state[src * S + c];
+  }
+  for (int c = lane; c < A; c += 16) a.action[row * A + c] = b.action[src * A + c];
+  if (lane == 0) a.reward[row] = b.reward[src];
+  if (lane == 1) a.not_done[row] = b.not_done[src];
 }
 
-// ---- exclusive scan of keep flags: pos[i] = #kept rows before i; tops[b] = kept rows in block b ----
+// ---- ring append in two launches ------------------------------------------------------------------------------------
+//  k_scan_blocks  per-1024-row exclusive scan of the keep flags (pos[i]) and block totals (tops[b]); the LAST block to
+//                 finish (atomic ticket) sums the totals, snapshots the ring's old {ptr, size} into the workspace and
+//                 commits the new ones (add_batch's single-wrap arithmetic, utils.py:43-92) -- all integer, deterministic.
+//  k_ring_scatter one row per 16-lane group: destination = old ptr + (rows kept before this one), wrapped once.
+// Workspace (int32): pos[M] | tops[nblocks] | meta[8] = {ticket, K, old_ptr lo/hi, ...}.  The ticket is left at 0.
 constexpr int SCAN_BLOCK = 1024;
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_blocks(const uint8_t* keep, long long M, int32_t* pos, int32_t* tops) {
+struct ScanArgs {
+  const uint8_t* keep;
+  long long M, cap;
+  int32_t *pos, *tops, *meta;
+  long long* ptr_size;
+  int nblocks;
+};
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_blocks(ScanArgs a) {
   __shared__ int32_t sm[SCAN_BLOCK];
+  __shared__ int last;
   const long long i = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  const int32_t f = (i < M) ? (keep ? (keep[i] != 0) : 1) : 0;
+  const int32_t f = (i < a.M) ? (a.keep ? (a.keep[i] != 0) : 1) : 0;
   sm[threadIdx.x] = f;
   __syncthreads();
   for (int o = 1; o < SCAN_BLOCK; o <<= 1) {        // Hillis-Steele inclusive scan
@@ -64,36 +88,48 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_blocks(const uint8_t* keep,
     sm[threadIdx.x] += v;
     __syncthreads();
   }
-  if (i < M) pos[i] = sm[threadIdx.x] - f;
-  if (threadIdx.x == SCAN_BLOCK - 1) tops[blockIdx.x] = sm[threadIdx.x];
-}
-
-// single block: exclusive scan of the block totals in place; tops[nblocks] = total kept
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tops(int32_t* tops, int nblocks) {
-  __shared__ int32_t sm[SCAN_BLOCK];
-  const int32_t f = ((int)threadIdx.x < nblocks) ? tops[threadIdx.x] : 0;
-  sm[threadIdx.x] = f;
+  if (i < a.M) a.pos[i] = sm[threadIdx.x] - f;
+  if (threadIdx.x == SCAN_BLOCK - 1) {
+    a.tops[blockIdx.x] = sm[threadIdx.x];
+    __threadfence();                                 // the total is visible before the ticket is taken
+    last = atomicAdd(&a.meta[0], 1) == a.nblocks - 1;
+  }
   __syncthreads();
-  for (int o = 1; o < SCAN_BLOCK; o <<= 1) {
-    const int32_t v = (threadIdx.x >= (unsigned)o) ? sm[threadIdx.x - o] : 0;
-    __syncthreads();
-    sm[threadIdx.x] += v;
+  if (!last) return;
+  __threadfence();
+  int32_t s = 0;                                     // this block finished last: K = sum of the block totals
+  for (int b = threadIdx.x; b < a.nblocks; b += SCAN_BLOCK) s += a.tops[b];
+  __syncthreads();
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = SCAN_BLOCK / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
     __syncthreads();
   }
-  if ((int)threadIdx.x < nblocks) tops[threadIdx.x] = sm[threadIdx.x] - f;
-  if (threadIdx.x == SCAN_BLOCK - 1) tops[nblocks] = sm[threadIdx.x];
+  if (threadIdx.x == 0) {
+    const long long K = sm[0];
+    const long long ptr = a.ptr_size[0], size = a.ptr_size[1];
+    a.meta[1] = (int32_t)K;
+    a.meta[2] = (int32_t)(ptr & 0xFFFFFFFFLL); a.meta[3] = (int32_t)(ptr >> 32);
+    const long long end = (ptr + K < a.cap) ? ptr + K : a.cap;
+    const long long used = end - ptr;
+    long long nptr = end % a.cap;
+    const long long nsize = size + used < a.cap ? size + used : a.cap;
+    if (nptr == 0) nptr = K - used;                  // utils.py:74-91
+    a.ptr_size[0] = nptr;
+    a.ptr_size[1] = nsize;
+    a.meta[0] = 0;                                   // ticket ready for the next call
+  }
 }
 
 struct RingArgs {
   float *b_state, *b_action, *b_next_state, *b_reward, *b_not_done;
   long long cap;
-  long long* ptr_size;
   int S, A;
   const float *obs, *act, *next_obs, *reward;
   const uint8_t *terminal, *keep;
   long long M;
-  const int32_t *pos, *tops;
-  int nblocks;
+  const int32_t *pos, *tops, *meta;
 };
 
 __device__ __forceinline__ long long ring_dst(long long j, long long ptr, long long K, long long cap) {
@@ -103,33 +139,49 @@ __device__ __forceinline__ long long ring_dst(long long j, long long ptr, long l
 }
 
 __global__ __launch_bounds__(256) void k_ring_scatter(RingArgs a) {
-  const int W = 2 * a.S + a.A + 2;
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= a.M * W) return;
-  const long long i = gid / W;
-  const int c = (int)(gid - i * W);
-  if (a.keep && !a.keep[i]) return;
-  const long long j = (long long)a.pos[i] + a.tops[i / SCAN_BLOCK];
-  const long long K = a.tops[a.nblocks];
-  const long long d = ring_dst(j, a.ptr_size[0], K, a.cap);
+  __shared__ int32_t sm[4];
+  const int lane = threadIdx.x & 15;
+  const long long row0 = (long long)blockIdx.x * 16;           // 16 rows per workgroup, all inside one scan block
+  const int sb = (int)(row0 / SCAN_BLOCK);
+  int32_t part = 0;                                            // rows kept in the scan blocks before this one
+  for (int b = threadIdx.x; b < sb; b += 256) part += a.tops[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = part;
+  __syncthreads();
+  const long long base = (long long)sm[0] + sm[1] + sm[2] + sm[3];
+  const long long i = row0 + (threadIdx.x >> 4);
+  if (i >= a.M || (a.keep && !a.keep[i])) return;
+  const long long K = a.meta[1];
+  const long long ptr = ((long long)(uint32_t)a.meta[2]) | ((long long)a.meta[3] << 32);
+  const long long d = ring_dst(base + a.pos[i], ptr, K, a.cap);
   const int S = a.S, A = a.A;
-  if (c < S) a.b_state[d * S + c] = a.obs[i * S + c];
-  else if (c < S + A) a.b_action[d * A + (c - S)] = a.act[i * A + (c - S)];
-  else if (c < 2 * S + A) a.b_next_state[d * S + (c - S - A)] = a.next_obs[i * S + (c - S - A)];
-  else if (c == 2 * S + A) a.b_reward[d] = a.reward[i];
-  else a.b_not_done[d] = 1.f - (float)(a.terminal[i] != 0);
+  for (int c = lane; c < S; c += 16) {
+    a.b_state[d * S + c] = a.obs[i * S + c];
+    a.b_next_state[d * S + c] = a.next_obs[i * S + c];
+  }
+  for (int c = lane; c < A; c += 16) a.b_action[d * A + c] = a.act[i * A + c];
+  if (lane == 0) a.b_reward[d] = a.reward[i];
+  if (lane == 1) a.b_not_done[d] = 1.f - (float)(a.terminal[i] != 0);
 }
 
-__global__ void k_ring_commit(long long* ptr_size, long long cap, const int32_t* tops, int nblocks) {
-  const long long K = tops[nblocks];
-  const long long ptr = ptr_size[0], size = ptr_size[1];
-  const long long end = (ptr + K < cap) ? ptr + K : cap;
-  const long long used = end - ptr;
-  long long nptr = end % cap;
-  long long nsize = size + used < cap ? size + used : cap;
-  if (nptr == 0) nptr = K - used;                               // utils.py:74-91
-  ptr_size[0] = nptr;
-  ptr_size[1] = nsize;
+int launch_ring_append(float* b_state, float* b_action, float* b_next_state, float* b_reward, float* b_not_done, long long cap,
+                       long long* ptr_size, int S, int A, const float* obs, const float* act, const float* next_obs,
+                       const float* reward, const uint8_t* terminal, const uint8_t* keep, long long M, int32_t* scan_ws,
+                       hipStream_t st) {
+  const int nblocks = (int)cdiv(M, SCAN_BLOCK);
+  int32_t* pos = scan_ws;
+  int32_t* tops = scan_ws + M;
+  int32_t* meta = tops + nblocks;
+  ScanArgs sa{keep, M, cap, pos, tops, meta, ptr_size, nblocks};
+  if (hipMemsetAsync(meta, 0, 8 * sizeof(int32_t), st) != hipSuccess) return fail(MOBODY_E_LAUNCH, "ring append: memset failed");
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nblocks), dim3(SCAN_BLOCK), 0, st, sa);
+  MB_LAUNCH_OK("k_scan_blocks");
+  RingArgs a{b_state, b_action, b_next_state, b_reward, b_not_done, cap, S, A, obs, act, next_obs, reward, terminal, keep, M,
+             pos, tops, meta};
+  hipLaunchKernelGGL(k_ring_scatter, dim3((unsigned)cdiv(M, 16)), dim3(256), 0, st, a);
+  MB_LAUNCH_OK("k_ring_scatter");
+  return 0;
 }
 
 }  // namespace mobody
@@ -152,8 +204,7 @@ extern "C" int mobody_gather_batch(const MobodyBufferView* bufs, const int32_t* 
   if (N == 0) return 0;
   MB_REQUIRE(state && action && next_state && reward && not_done, "mobody_gather_batch: null output");
   a.state = state; a.action = action; a.next_state = next_state; a.reward = reward; a.not_done = not_done;
-  const long long total = N * (2 * S + A + 2);
-  hipLaunchKernelGGL(k_gather, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream), a);
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)cdiv(N, 16)), dim3(256), 0, as_stream(stream), a);
   MB_LAUNCH_OK("k_gather");
   return 0;
 }
@@ -169,22 +220,8 @@ extern "C" int mobody_ring_append(float* b_state, float* b_action, float* b_next
   MB_REQUIRE(M <= (int64_t)SCAN_BLOCK * SCAN_BLOCK, "mobody_ring_append: at most %d rows per call", SCAN_BLOCK * SCAN_BLOCK);
   MB_REQUIRE(b_state && b_action && b_next_state && b_reward && b_not_done && ptr_size && obs && act && next_obs && reward &&
                  terminal && scan_ws, "mobody_ring_append: null pointer");
-  hipStream_t st = as_stream(stream);
-  const int nblocks = (int)cdiv(M, SCAN_BLOCK);
-  int32_t* pos = scan_ws;
-  int32_t* tops = scan_ws + M;
-  hipLaunchKernelGGL(k_scan_blocks, dim3(nblocks), dim3(SCAN_BLOCK), 0, st, keep, (long long)M, pos, tops);
-  MB_LAUNCH_OK("k_scan_blocks");
-  hipLaunchKernelGGL(k_scan_tops, dim3(1), dim3(SCAN_BLOCK), 0, st, tops, nblocks);
-  MB_LAUNCH_OK("k_scan_tops");
-  RingArgs a{b_state, b_action, b_next_state, b_reward, b_not_done, cap, (long long*)ptr_size, S, A, obs, act, next_obs,
-             reward, terminal, keep, M, pos, tops, nblocks};
-  const long long total = M * (2 * S + A + 2);
-  hipLaunchKernelGGL(k_ring_scatter, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, a);
-  MB_LAUNCH_OK("k_ring_scatter");
-  hipLaunchKernelGGL(k_ring_commit, dim3(1), dim3(1), 0, st, (long long*)ptr_size, (long long)cap, tops, nblocks);
-  MB_LAUNCH_OK("k_ring_commit");
-  return 0;
+  return launch_ring_append(b_state, b_action, b_next_state, b_reward, b_not_done, cap, (long long*)ptr_size, S, A, obs, act,
+                            next_obs, reward, terminal, keep, M, scan_ws, as_stream(stream));
 }
 
 extern "C" int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64_t* counts, int nbuf, int S, int A,
@@ -206,8 +243,7 @@ extern "C" int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64
   if (N == 0) return 0;
   MB_REQUIRE(state && action && next_state && reward && not_done, "mobody_gather_batch_rng: null output");
   a.state = state; a.action = action; a.next_state = next_state; a.reward = reward; a.not_done = not_done;
-  const long long total = N * (2 * S + A + 2);
-  hipLaunchKernelGGL(k_gather, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, as_stream(stream), a);
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)cdiv(N, 16)), dim3(256), 0, as_stream(stream), a);
   MB_LAUNCH_OK("k_gather");
   return 0;
 }

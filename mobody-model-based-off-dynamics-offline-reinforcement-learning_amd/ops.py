@@ -375,3 +375,18 @@ def dyn_validate(blob, S, A, obs, act, next_obs, rew, use_trg, ws=None):
                                      ptr(_f32(rew).reshape(-1).contiguous()), B, int(bool(use_trg)), ptr(out), ptr(ws),
                                      cur_stream()), "mobody_dyn_validate")
     return out
+
+
+def rollout(dyn_blob, actor_blob, S, A, task_id, max_action, init_obs, H, elites, seed, call0, penalty_coef, use_penalty,
+            use_trg, env_filter, filter_bad_rollout, buf, cap, ptr_size, ws=None):
+    """H-step on-device rollout of `init_obs` appended to the ring `buf` (mobody_rollout).  Returns the workspace."""
+    B = init_obs.shape[0]
+    need = load().mobody_rollout_workspace(S, A, B)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1), dtype=torch.float32, device=init_obs.device)
+    el = (C.c_int32 * len(elites))(*[int(e) for e in elites])
+    check(load().mobody_rollout(ptr(dyn_blob), ptr(actor_blob), S, A, task_id, float(max_action), ptr(_f32(init_obs)), B, int(H),
+                                el, len(elites), seed, call0, float(penalty_coef), int(bool(use_penalty)), int(bool(use_trg)),
+                                float(env_filter), int(bool(filter_bad_rollout)), *[ptr(t) for t in buf], cap, ptr(ptr_size),
+                                ptr(ws), cur_stream()), "mobody_rollout")
+    return ws

@@ -123,3 +123,39 @@ def test_ring_append_random_sequences_vs_reference_arithmetic(dev):
             assert ps.cpu().tolist() == [ptr, size], (case, step, cap, M, K)
             for t, want in zip(buf, ref):
                 assert (t.cpu().numpy() == want).all(), (case, step)
+
+
+def test_on_device_rollout_equals_the_step_by_step_composition(dev):
+    """`mobody_rollout` (H steps, fused mask, two-launch append) == the same rollout assembled from the stand-alone entry
+    points (actor forward -> mobody_dyn_step -> mobody_rollout_mask -> mobody_ring_append), bit for bit, into a ring that
+    wraps (cap < rows appended)."""
+    import golden_util as gu
+    from mobody_amd import ops, packing
+    S, A, B, H, cap = 17, 6, 700, 4, 1500
+    p = gu.gi.dyn_params(201, S, A)
+    p["transition3.bias"][:, 0, 0] += np.float32(0.85)
+    pa, _, _ = gu.policy_params(301, S, A)
+    dyn = packing.pack_dynamics(p, S, A, dev)
+    actor = packing.pack_mlp([{k[len("network."):]: v for k, v in pa.items()}], S, A, dev)
+    init = torch.from_numpy(gu.gi.walker_like_obs(np.random.default_rng(4), B, S)).to(dev)
+    elites = (0, 2, 3, 5, 6)
+
+    def ring():
+        z = lambda n: torch.zeros(cap, n, device=dev)
+        return (z(S), z(A), z(S), z(1), z(1)), torch.tensor([100, 100], dtype=torch.int64, device=dev)
+
+    buf1, ps1 = ring()
+    ops.rollout(dyn, actor, S, A, 4, 1.0, init, H, elites, 21, 7, 0.1, True, True, 0.5, True, buf1, cap, ps1)
+    buf2, ps2 = ring()
+    obs, alive = init, None
+    keep = torch.empty(B, dtype=torch.uint8, device=dev)
+    for t in range(H):
+        act = ops.mlp3_forward(actor, S, A, 1, obs, out_mode=1, max_action=1.0)[0]
+        r = ops.dyn_step(dyn, S, A, 4, obs, act, alive=alive, elites=elites, seed=21, call=7 + t, penalty_coef=0.1)
+        nalive = torch.empty(B, dtype=torch.uint8, device=dev)
+        ops.rollout_mask(alive, r["terminal"], r["penalty"], 0.5, True, keep, nalive)
+        ops.ring_append(buf2, cap, ps2, S, A, obs, act, r["next_obs"], r["reward"], r["terminal"], keep)
+        obs, alive = r["next_obs"], nalive
+    assert ps1.tolist() == ps2.tolist() and ps1.tolist()[1] == cap          # the ring filled up and wrapped
+    for a, b in zip(buf1, buf2):
+        assert torch.equal(a, b)
