@@ -88,7 +88,7 @@ def spawn_ranks(args):
 
 
 # ------------------------------------------------------------------------------------------------ GPU side
-def build(dev, c, graph):
+def build(dev, c, graph, mfma="f32"):
     import numpy as np
     import torch
     from mobody_amd import engine, synthetic
@@ -101,7 +101,7 @@ def build(dev, c, graph):
     # the SAME seeds on every rank: the mirror folds the rank into its index / noise streams and broadcasts rank 0's
     # replica before the first step, so a caller cannot get either wrong
     cfg = engine.default_config(S, A, rng="device", seed=0, penalty_type=c["penalty_type"], batch_size=bs, graph=graph,
-                                src_rollout_length=c["H"], trg_rollout_length=c["H"])
+                                src_rollout_length=c["H"], trg_rollout_length=c["H"], mfma=mfma)
     torch.manual_seed(0); np.random.seed(0)
     pol = call_algo("mobody", cfg, 3, dev)
     src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=1000000, rng="device", seed=100), 1000000, task, 0)
@@ -278,6 +278,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch_size", type=int, default=None, help="override the config's per-GPU batch size")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--mfma", default="f32", choices=["f32", "bf16x3", "bf16x2", "bf16"],
+                    help="MFMA mode of the 256 x 256 forward layers: exact fp32 (parity mode) or a split-precision bf16 mode")
     ap.add_argument("--graph", type=int, default=1, help="HIP-graph replay of the steady-state step: 0 never, 1 always, 2 auto (minibatches under 4096 rows); with N > 1 ranks the segments between the three all-reduces are replayed")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -304,7 +306,7 @@ def main():
         c["bs"] = args.batch_size
     S, A, bs = c["S"], c["A"], c["bs"]
     N, Nt = int(2.5 * bs), 2 * bs
-    pol, src, tar, cfg = build(dev, c, args.graph)
+    pol, src, tar, cfg = build(dev, c, args.graph, args.mfma)
 
     def barrier():
         if world > 1:
@@ -315,6 +317,8 @@ def main():
         pol.train(src, tar, bs, None, None)
     scaled_refresh(pol, src, tar, bs, args.steps)         # warm the scaled refresh's shapes too
     barrier()
+    import gc
+    gc.collect(); gc.disable()                            # a generation-2 collection inside the timed loop is a 40 ms host stall
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     t0 = time.perf_counter()
     ev[0].record()
@@ -324,6 +328,7 @@ def main():
     rolled = scaled_refresh(pol, src, tar, bs, args.steps)
     barrier()
     t1 = time.perf_counter()
+    gc.enable()
     t = torch.tensor([t1 - t0, ev[0].elapsed_time(ev[1]) * 1e-3], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -379,9 +384,11 @@ def main():
             "metric": "transitions/sec (minibatch rows through train(), refresh amortised at 1/5000) + grad-steps/sec",
             "value": N * world * args.steps / dt, "unit": "transitions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
             "config": {"workload": f"{args.config}: {c['label']} (S={S} A={A}, ensemble 7, rollout_len {c['H']}, N={N} rows per "
-                                   f"train() step: src|tar|fake = {bs}|{bs}|{bs // 2}), fp32 MFMA",
+                                   f"train() step: src|tar|fake = {bs}|{bs}|{bs // 2}), "
+                                   + ("exact fp32 MFMA" if args.mfma == "f32" else f"256x256 forward layers on the {args.mfma} split-precision MFMA core, "
+                                      "everything else exact fp32 MFMA"),
                        "name": args.config, "rows_per_step_per_gpu": N, "parallelism": f"dp{world}", "hip_graph": graph_on},
             "grad_steps_per_sec": args.steps / dt,
             "grad_steps_per_sec_refresh_excluded": args.steps / dt_steps,

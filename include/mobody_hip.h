@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MOBODY_ABI_VERSION 1
+#define MOBODY_ABI_VERSION 2
 #define MOBODY_E_ARG (-1)      /* bad argument (dims, null pointer, unsupported size) */
 #define MOBODY_E_LAUNCH (-2)   /* hipLaunch / runtime error */
 #define MOBODY_E_UNSUPPORTED (-3)
@@ -78,13 +78,17 @@ typedef struct MobodyDynLayout {
  * Parameter blob, per member: W1[Kp1][256] b1[256] W2[256][256] b2[256] W3[256][Np3] b3[Np3]
  * (W stored [in][out], i.e. the transpose of nn.Linear.weight).  The same layout is used for
  * gradients and both Adam moments.  The "T" blob holds the transposes the backward pass
- * streams as MFMA B operands: W3T[Np3][256] W2T[256][256] W1T[256][Np1t] per member. */
+ * streams as MFMA B operands: W3T[Np3][256] W2T[256][256] W1T[256][Np1t] per member, followed by the bf16 planes of
+ * W2 and W2^T that the split-precision modes stream (precision 1 "bf16": one plane, 2 "bf16x2": two planes / three
+ * products, 3 "bf16x3": three planes / six products; 0 = exact fp32 MFMA, the default and the parity mode). */
 typedef struct MobodyMlpLayout {
   int32_t in_dim, out_dim, members, Kp1, Np3, Np1t;
   int64_t w1, b1, w2, b2, w3, b3;   /* float offsets inside one member */
   int64_t member_floats, total_floats;
   int64_t w3t, w2t, w1t;            /* float offsets inside one member of the T blob */
   int64_t t_member_floats, t_total_floats;
+  int64_t w2p, w2tp;                /* float offsets (inside one member of the T blob) of the bf16 planes of W2 and W2^T:
+                                       [3 planes][32][256][8] bf16 each, x = x0 + x1 + x2 (split-precision modes) */
 } MobodyMlpLayout;
 
 const char* mobody_last_error(void);
@@ -107,8 +111,14 @@ int mobody_rng_index(uint32_t seed, uint32_t stream_id, uint32_t call, int64_t n
 
 /* ---- ensemble dynamics ----------------------------------------------------------------- */
 /* mean[E][B][S] = forward_trg/forward_src(obs, act) in inference mode. */
-int mobody_dyn_forward(const float* dyn_blob, int S, int A, const float* obs, const float* act, int64_t B,
-                       int use_trg, float* mean, void* stream);
+int mobody_dyn_forward(const float* dyn_blob, const float* dyn_planes, int precision, int S, int A, const float* obs,
+                       const float* act, int64_t B, int use_trg, float* mean, void* stream);
+/* dyn_planes / precision (here and in mobody_dyn_step / mobody_rollout): 0 = exact fp32 MFMA (planes may be NULL);
+ * 1 bf16, 2 bf16x2, 3 bf16x3 = the three 256 x 256 layers of every member (zs2, transition2, reward_model2) on the
+ * split-precision bf16 core, streaming the planes mobody_dyn_planes built from the blob
+ * (mobody_dyn_planes_floats() floats: [3 layers][7 members][3 planes][65536] bf16). */
+int64_t mobody_dyn_planes_floats(void);
+int mobody_dyn_planes(const float* dyn_blob, int S, int A, float* planes, void* stream);
 
 /* floats of scratch mobody_dyn_step needs for a batch of B rows */
 int64_t mobody_dyn_step_workspace(int S, int A, int64_t B);
@@ -121,7 +131,8 @@ int64_t mobody_dyn_step_workspace(int S, int A, int64_t B);
  *   elites     HOST array of n_elites member ids (MOBODYModule.elites), used when elite_idx is NULL
  *   outputs    next_obs[B][S], reward[B], terminal[B] (uint8), penalty[B], raw_reward[B] (nullable)
  *   mean_out   optional [E][B][S] copy of the ensemble means (info['samples']) */
-int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, const float* obs, const float* act, int64_t B,
+int mobody_dyn_step(const float* dyn_blob, const float* dyn_planes, int precision, int S, int A, int task,
+                    const float* obs, const float* act, int64_t B,
                     const float* noise, const int32_t* elite_idx, const uint8_t* alive, const int32_t* elites,
                     int n_elites, uint32_t seed,
                     uint32_t call, float penalty_coef, int use_penalty, int use_trg, float* next_obs, float* reward,
@@ -137,7 +148,8 @@ int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, const float* 
  * NB quirk Q1: MOBODY.rollout passes its `use_trg` argument in step()'s `use_penalty` slot -- callers mirror that here.
  * workspace: mobody_rollout_workspace(S, A, B) floats. */
 int64_t mobody_rollout_workspace(int S, int A, int64_t B);
-int mobody_rollout(const float* dyn_blob, const float* actor_blob, int S, int A, int task, float max_action,
+int mobody_rollout(const float* dyn_blob, const float* dyn_planes, const float* actor_blob, const float* actor_blob_T,
+                   int precision, int S, int A, int task, float max_action,
                    const float* init_obs, int64_t B, int H, const int32_t* elites, int n_elites, uint32_t seed, uint32_t call0,
                    float penalty_coef, int use_penalty, int use_trg, float env_filter, int filter_bad_rollout, float* b_state,
                    float* b_action, float* b_next_state, float* b_reward, float* b_not_done, int64_t cap, int64_t* ptr_size,
@@ -167,9 +179,11 @@ int mobody_counter_add(int64_t* counter, int n, int64_t inc, void* stream);
 /* x = concat(src0[rows][n0], src1[rows][n1]) (src1 may be NULL), n0+n1 == in_dim.
  * out_mode 0: out[m][rows][out_dim] raw;  1: max_action*tanh(.) (Policy.forward mobody.py:68-72).
  * save_x [rows][Kp1], save_h1/save_h2 [members][rows][256] are optional (backward inputs). */
-int mobody_mlp3_forward(const float* blob, int in_dim, int out_dim, int members, const float* src0, int n0,
-                        const float* src1, int n1, int64_t rows, int out_mode, float max_action, float* out,
-                        float* save_x, float* save_h1, float* save_h2, void* stream);
+int mobody_mlp3_forward(const float* blob, const float* blob_T, int precision, int in_dim, int out_dim, int members,
+                        const float* src0, int n0, const float* src1, int n1, int64_t rows, int out_mode,
+                        float max_action, float* out, float* save_x, float* save_h1, float* save_h2, void* stream);
+/* blob_T / precision: 0 = exact fp32 MFMA (blob_T may be NULL); 1..3 = the split-precision modes, which stream W2's
+ * bf16 planes from the T blob (mobody_mlp_transpose builds them, the Adam kernels keep them current). */
 
 /* ---- replay gather / ring append ------------------------------------------------------- */
 typedef struct MobodyBufferView {   /* ReplayBuffer fields, algo/utils.py:19-23 */
@@ -213,6 +227,7 @@ typedef struct MobodyTrainDims {
 typedef struct MobodyHyper {
   float gamma, tau, max_action, weight, bc_coef;
   int32_t q_weighted, scale_q;
+  int32_t precision;   /* MFMA mode of the 256 x 256 forward layers: 0 exact fp32 (default, parity), 1 bf16, 2 bf16x2, 3 bf16x3 */
 } MobodyHyper;
 
 /* floats of scratch the training calls need.  The SAME workspace has to be handed to mobody_actor_forward and the
@@ -222,10 +237,12 @@ int64_t mobody_train_workspace(const MobodyTrainDims* d);
 
 /* Critic loss + gradients (A.2): grad_q (MobodyMlpLayout(S+A,1,2) layout) and loss_out[0] = L_Q of
  * the LOCAL rows scaled by 1/N_global (sum over ranks == global loss). */
-int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* q_blob,
-                       const float* q_blob_T, const float* qtarg_blob, const float* state, const float* action,
-                       const float* next_state, const float* reward, const float* not_done, const float* q_next,
-                       float* grad_q, float* loss_out, float* workspace, int policy_forward, void* stream);
+int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* actor_blob_T,
+                       const float* q_blob, const float* q_blob_T, const float* qtarg_blob, const float* qtarg_blob_T,
+                       const float* state, const float* action, const float* next_state, const float* reward,
+                       const float* not_done, const float* q_next, float* grad_q, float* loss_out, float* workspace,
+                       int policy_forward, void* stream);
+/* actor_blob_T / qtarg_blob_T are only read when h->precision != 0 (their W2 planes); NULL is fine at precision 0. */
 /* policy_forward != 0 (needs q_next == NULL): the target-Q launch also evaluates pi(s) with its saves for the coming
  * mobody_actor_forward(..., policy_ready = 1) on the same workspace -- the actor does not change in between, and
  * the merged launch fills the chip better than the two it replaces.
@@ -236,17 +253,18 @@ int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const flo
 /* Single-GPU form of mobody_critic_step + mobody_adam_polyak (mobody.py:540-552): the gradient reduction applies the
  * Adam step (1-based t, or a device word t_dev) and the Polyak update of qtarg_blob (tau from `h`) itself, so the
  * gradient blob is never written -- one launch and one gradient round trip fewer.  Bit-identical to the two calls. */
-int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, float* q_blob,
-                         float* q_blob_T, float* qtarg_blob, const float* state, const float* action,
-                         const float* next_state, const float* reward, const float* not_done, const float* q_next,
-                         float* m, float* v, int64_t t, const int64_t* t_dev, float lr, float* loss_out,
-                         float* workspace, int policy_forward, void* stream);
+int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* actor_blob_T,
+                         float* q_blob, float* q_blob_T, float* qtarg_blob, float* qtarg_blob_T, const float* state,
+                         const float* action, const float* next_state, const float* reward, const float* not_done,
+                         const float* q_next, float* m, float* v, int64_t t, const int64_t* t_dev, float lr,
+                         float* loss_out, float* workspace, int policy_forward, void* stream);
+/* qtarg_blob_T (nullable): the target net's T blob; when given, the W2 planes of the target follow the Polyak update. */
 
 /* Actor phase, part 1: forwards + the two batch statistics stats[0]=sum|min Q(s,pi(s))|,
  * stats[1]=sum|min Q(s_t,a_t)| over LOCAL rows (all-reduce them across ranks before part 2). */
-int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* q_blob,
-                         const float* state, const float* action, float* stats, float* workspace, int policy_ready,
-                         void* stream);
+int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* actor_blob_T,
+                         const float* q_blob, const float* q_blob_T, const float* state, const float* action, float* stats,
+                         float* workspace, int policy_ready, void* stream);
 /* policy_ready != 0: pi(s) and its saves are already in the workspace (mobody_critic_step(..., policy_forward = 1)). */
 
 /* Actor phase, part 2: grad_actor (MobodyMlpLayout(S,A,1)) and loss_out[0]=L_pi, [1]=L_BC (local share). */
@@ -272,12 +290,14 @@ int mobody_value_loss_grad(const float* qt, const float* v, int64_t N, int64_t N
  * transposed blob used by the backward kernels (blob_T may be NULL). grad_scale multiplies the
  * gradient first (1/world for an all-reduced SUM). */
 int mobody_adam_polyak(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad, float* m,
-                       float* v, float* target, int64_t t, float lr, float tau, float grad_scale, void* stream);
+                       float* v, float* target, float* target_T, int64_t t, float lr, float tau, float grad_scale,
+                       void* stream);
+/* target_T (nullable): T blob of the target net, whose W2 planes then follow the Polyak update (split-precision modes). */
 
 /* Same, with the 1-based step count read from DEVICE memory (t_dev[0]) so that a captured HIP graph advances
  * without new kernel arguments (bias corrections are formed in double on the device). */
 int mobody_adam_polyak_dev(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad,
-                           float* m, float* v, float* target, const int64_t* t_dev, float lr, float tau,
+                           float* m, float* v, float* target, float* target_T, const int64_t* t_dev, float lr, float tau,
                            float grad_scale, void* stream);
 
 /* PAR reward shaping: reward[i] -= coef * mean_d (next_state_true[i][d] - next_state_model[i][d])^2  (mobody.py:428-434) */

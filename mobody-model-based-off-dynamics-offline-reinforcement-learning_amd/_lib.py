@@ -30,7 +30,7 @@ class MobodyMlpLayout(C.Structure):
     _fields_ = [("in_dim", i32), ("out_dim", i32), ("members", i32), ("Kp1", i32), ("Np3", i32), ("Np1t", i32),
                 ("w1", i64), ("b1", i64), ("w2", i64), ("b2", i64), ("w3", i64), ("b3", i64),
                 ("member_floats", i64), ("total_floats", i64), ("w3t", i64), ("w2t", i64), ("w1t", i64),
-                ("t_member_floats", i64), ("t_total_floats", i64)]
+                ("t_member_floats", i64), ("t_total_floats", i64), ("w2p", i64), ("w2tp", i64)]
 
 
 class MobodyPretrainLayout(C.Structure):
@@ -51,7 +51,10 @@ class MobodyTrainDims(C.Structure):
 
 class MobodyHyper(C.Structure):
     _fields_ = [("gamma", f32), ("tau", f32), ("max_action", f32), ("weight", f32), ("bc_coef", f32),
-                ("q_weighted", i32), ("scale_q", i32)]
+                ("q_weighted", i32), ("scale_q", i32), ("precision", i32)]
+
+
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x2": 2, "bf16x3": 3}
 
 
 TERM_IDS = {"never": 0, "halfcheetah": 1, "hopper": 2, "ant": 3, "walker2d": 4, "humanoid": 5, "pen": 6}
@@ -66,18 +69,20 @@ PROTOTYPES = {
     "mobody_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(i64), C.c_int]),
     "mobody_rng_normal": (C.c_int, [u32, u32, u32, i64, vp, vp]),
     "mobody_rng_index": (C.c_int, [u32, u32, u32, i64, u32, vp, vp]),
-    "mobody_dyn_forward": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp, vp]),
+    "mobody_dyn_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp, vp]),
+    "mobody_dyn_planes_floats": (i64, []),
+    "mobody_dyn_planes": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "mobody_dyn_step_workspace": (i64, [C.c_int, C.c_int, i64]),
-    "mobody_dyn_step": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, i64, vp, vp, vp, C.POINTER(i32), C.c_int,
+    "mobody_dyn_step": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, i64, vp, vp, vp, C.POINTER(i32), C.c_int,
                                   u32, u32, f32, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mobody_rollout_workspace": (i64, [C.c_int, C.c_int, i64]),
-    "mobody_rollout": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, vp, i64, C.c_int, C.POINTER(i32), C.c_int, u32, u32, f32,
+    "mobody_rollout": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, i64, C.c_int, C.POINTER(i32), C.c_int, u32, u32, f32,
                                  C.c_int, C.c_int, f32, C.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp]),
     "mobody_termination": (C.c_int, [C.c_int, vp, i64, C.c_int, vp, vp]),
     "mobody_rollout_mask": (C.c_int, [vp, vp, vp, f32, C.c_int, i64, vp, vp, vp]),
     "mobody_sample_indices": (C.c_int, [u32, u32, vp, i64, i64, vp, vp, vp]),
     "mobody_counter_add": (C.c_int, [vp, C.c_int, i64, vp]),
-    "mobody_mlp3_forward": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, i64, C.c_int, f32, vp,
+    "mobody_mlp3_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, i64, C.c_int, f32, vp,
                                       vp, vp, vp, vp]),
     "mobody_gather_batch": (C.c_int, [C.POINTER(MobodyBufferView), C.POINTER(vp), C.POINTER(i64), C.c_int, C.c_int,
                                       C.c_int, vp, vp, vp, vp, vp, vp]),
@@ -86,19 +91,19 @@ PROTOTYPES = {
     "mobody_ring_append": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, vp,
                                      vp]),
     "mobody_train_workspace": (i64, [C.POINTER(MobodyTrainDims)]),
-    "mobody_critic_step": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp,
+    "mobody_critic_step": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                      vp, vp, vp, vp, vp, vp, C.c_int, vp]),
-    "mobody_critic_update": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp,
+    "mobody_critic_update": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, i64, vp, f32, vp, vp, C.c_int, vp]),
     "mobody_actor_update": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, vp, i64, vp, f32, vp, vp, vp]),
     "mobody_value_loss_grad": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp]),
-    "mobody_actor_forward": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp,
+    "mobody_actor_forward": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp, vp,
                                        C.c_int, vp]),
     "mobody_actor_backward": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp,
                                         vp, vp, vp, vp, vp, vp]),
-    "mobody_adam_polyak": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp]),
-    "mobody_adam_polyak_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
+    "mobody_adam_polyak": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp]),
+    "mobody_adam_polyak_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
     "mobody_par_penalty": (C.c_int, [vp, vp, vp, f32, i64, C.c_int, vp]),
     "mobody_mlp3_backward_workspace": (i64, [C.c_int, C.c_int, C.c_int, i64]),
     "mobody_mlp3_backward": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, i64, vp, vp, vp]),
@@ -138,7 +143,7 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.mobody_abi_version() != 1:
+    if lib.mobody_abi_version() != 2:
         raise ImportError("libmobody_hip.so ABI version mismatch")
     _lib = lib
     return lib

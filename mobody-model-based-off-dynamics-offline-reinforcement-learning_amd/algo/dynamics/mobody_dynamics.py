@@ -59,6 +59,7 @@ class MOBODYEnsembleDynamics(object):
         self.cycle_loss_coef = config["cycle_loss_coef"]
         self.encode_trg_diff = getattr(model, "encode_trg_diff", 0)
         self.rng, self.seed = rng, int(seed)
+        self.precision = ops.prec_id(str(config.get("mfma", "f32")))     # MFMA mode of step(): 0 exact fp32 | bf16 / bf16x2 / bf16x3
         self._calls = 0
         self.noise_fn = None          # optional hook: noise_fn((7, B, S)) -> unit normals (tests)
         self.train_noise_fn = None    # optional hook: b -> (noise6[6,7,b,16], noise7[7,b,S]) device tensors (tests)
@@ -93,7 +94,7 @@ class MOBODYEnsembleDynamics(object):
                             seed=(self.seed + dp.rank_salt()) & 0xFFFFFFFF, call=self._calls,
                             penalty_coef=float(self._penalty_coef or 0.0),
                             use_penalty=bool(use_penalty), use_trg=bool(use_trg), want_mean=want_mean,
-                            workspace=self._ws)
+                            workspace=self._ws, planes=m.planes() if self.precision else None, precision=self.precision)
 
     @torch.no_grad()
     def step(self, obs, action, use_penalty=True, use_trg=True):

@@ -54,7 +54,7 @@ class MOBODYModule(object):
         self._p["max_logvar_latent"] = torch.ones(LATENT, device=self.device) * 20
         self._p["min_logvar_latent"] = torch.ones(LATENT, device=self.device) * -20
         self._p["elites"] = torch.arange(self.num_elites, device=self.device)
-        self._blob = None
+        self._blob, self._planes = None, None
         self._train, self._train_ahead = None, False
         self.layer_names = list(dims)                              # module_list order, mobody_module.py:97-150
 
@@ -166,10 +166,20 @@ class MOBODYModule(object):
         self._sync_from_train()
         if self._blob is None:
             self._blob = packing.pack_dynamics(self._p, self.obs_dim, self.action_dim, self.device)
+            self._planes = None
         return self._blob
 
+    def planes(self):
+        """bf16 planes of the three 256 x 256 layers (split-precision modes), rebuilt with the packed blob."""
+        blob = self.packed()
+        if self._planes is None:
+            self._planes = ops.dyn_planes(blob, self.obs_dim, self.action_dim)
+        return self._planes
+
     def _fwd(self, state, action, use_trg):
-        mean = ops.dyn_forward(self.packed(), self.obs_dim, self.action_dim, state, action, use_trg)
+        prec = ops.prec_id(self.config.get("mfma", "f32"))
+        mean = ops.dyn_forward(self.packed(), self.obs_dim, self.action_dim, state, action, use_trg,
+                               planes=self.planes() if prec else None, precision=prec)
         return mean, None, None        # (mean, zs_mu, zs_logvar): the latent stats are unused by the hot path
 
     def forward_trg(self, state, action):

@@ -78,7 +78,8 @@ class _PackedNet(object):
 
     def __call__(self, x, x2=None):
         x = torch.as_tensor(x, dtype=torch.float32).to(self.device)
-        o = ops.mlp3_forward(self.blob, self.in_dim, self.out_dim, self.members, x, x2, self.out_mode, self.max_action)
+        o = ops.mlp3_forward(self.blob, self.in_dim, self.out_dim, self.members, x, x2, self.out_mode, self.max_action,
+                             blob_T=self.blob_T, precision=getattr(self, "precision", 0))
         return o[0] if self.members == 1 else tuple(o[m] for m in range(self.members))
 
 
@@ -94,13 +95,15 @@ class _Adam(object):
         self.t += 1
         n = self.net
         ops.adam_polyak(n.in_dim, n.out_dim, n.members, n.blob, n.blob_T, self.grad, self.m, self.v,
-                        None if target is None else target.blob, self.t, self.lr, tau, grad_scale)
+                        None if target is None else target.blob, self.t, self.lr, tau, grad_scale,
+                        target_T=None if target is None else target.blob_T)
 
     def step_dev(self, t_dev, target=None, tau=-1.0):
         """Graph-capturable step: the 1-based step count is read from the device word `t_dev` (already advanced)."""
         n = self.net
         ops.adam_polyak_dev(n.in_dim, n.out_dim, n.members, n.blob, n.blob_T, self.grad, self.m, self.v,
-                            None if target is None else target.blob, t_dev, self.lr, tau, 1.0)
+                            None if target is None else target.blob, t_dev, self.lr, tau, 1.0,
+                            target_T=None if target is None else target.blob_T)
 
     def _unpack(self, blob):
         n = self.net
@@ -183,6 +186,9 @@ class MOBODY(object):
         self.penalty_type = config["penalty_type"]
         S, A = int(config["state_dim"]), int(config["action_dim"])
         self.S, self.A = S, A
+        # MFMA mode of the 256 x 256 forward layers: 'f32' exact (default, the parity mode) | 'bf16x3' | 'bf16x2' | 'bf16'
+        self.mfma = str(config.get("mfma", "f32"))
+        self.precision = ops.prec_id(self.mfma)
         self.rng = config.get("rng", "numpy")               # 'numpy' = reference index/elite streams; 'device' = Philox
         self.seed = int(config.get("seed", 0))
         self.fake_replay_buffer = utils.ReplayBuffer(S, A, self.device, rng=self.rng, seed=self.seed + 17)
@@ -195,6 +201,7 @@ class MOBODY(object):
         self._v_ws = None
         self.q_optimizer = _Adam(self.q_funcs, config["critic_lr"])
         self.policy_optimizer = _Adam(self.policy, config["actor_lr"])
+        self.policy.precision = self.precision             # select_action / rollouts at the configured precision
         self.classifier = _Classifier(S, A, self.device, config["gaussian_noise_std"], config["actor_lr"])
         self.dynamics = None
         self._ws, self._ws_key = None, None
@@ -360,7 +367,9 @@ class MOBODY(object):
                                     rollout_length, [int(e) for e in m.elites.tolist()],
                                     (dyn.seed + dp.rank_salt()) & 0xFFFFFFFF, dyn._calls + 1, float(dyn._penalty_coef or 0.0),
                                     use_trg, True, self.config["env_filter"], self.config["filter_bad_rollout"],   # quirk Q1
-                                    fb._fields(), fb.max_size, fb.ptr_size, getattr(self, "_roll_ws", None))
+                                    fb._fields(), fb.max_size, fb.ptr_size, getattr(self, "_roll_ws", None),
+                                    dyn_planes=m.planes() if dyn.precision else None, actor_blob_T=self.policy.blob_T,
+                                    precision=dyn.precision)
         dyn._calls += rollout_length
         fb._pull()
         return B * rollout_length
@@ -479,7 +488,7 @@ class MOBODY(object):
         opts = (self.q_optimizer, self.policy_optimizer)
         key = (batch_size, id(src), id(tar), src.state.data_ptr(), tar.state.data_ptr(), world, segmented,
                id(fb), fb.state.data_ptr(), fb.ptr_size.data_ptr(), tuple(t.data_ptr() for t in self._batch),
-               tuple((n.blob.data_ptr(), n.blob_T.data_ptr()) for n in nets),
+               tuple((n.blob.data_ptr(), n.blob_T.data_ptr()) for n in nets), self.precision,
                tuple((o.m.data_ptr(), o.v.data_ptr(), o.grad.data_ptr()) for o in opts),
                None if self._ws is None else self._ws.data_ptr(), self.dp_graph)
         if self._graph is None or self._graph_key != key:
@@ -629,7 +638,8 @@ class MOBODY(object):
             q_next = ops.mlp3_forward(self.v_func.blob, self.S, 1, 1, b[2]).view(N)
         ops.critic_step(dims, hyp, self.policy.blob, self.q_funcs.blob, self.q_funcs.blob_T, self.target_q_funcs.blob,
                         b, self.q_optimizer.grad, self._loss[0:1], self._ws, q_next=q_next,
-                        policy_forward=self._policy_rides_along())
+                        policy_forward=self._policy_rides_along(), actor_blob_T=self.policy.blob_T,
+                        qtarg_blob_T=self.target_q_funcs.blob_T)
 
     def _policy_rides_along(self):
         """pi(s) of the actor phase is evaluated in the critic phase's target-Q launch (the actor does not change in
@@ -647,7 +657,8 @@ class MOBODY(object):
             o.t += 1
         ops.critic_update(dims, hyp, self.policy.blob, self.q_funcs.blob, self.q_funcs.blob_T, self.target_q_funcs.blob, b,
                           o.m, o.v, o.t, o.lr, self._loss[0:1], self._ws, q_next=q_next, t_dev=t_dev,
-                          policy_forward=self._policy_rides_along())
+                          policy_forward=self._policy_rides_along(), actor_blob_T=self.policy.blob_T,
+                          qtarg_blob_T=self.target_q_funcs.blob_T)
 
     def actor_update(self, b, N, Nt, t_dev=None):
         dims, hyp = self._dims(N, Nt, N, Nt)
@@ -669,7 +680,7 @@ class MOBODY(object):
     def actor_stats(self, b, N, Nt, Ng, Ntg):
         dims, hyp = self._dims(N, Nt, Ng, Ntg)
         ops.actor_forward(dims, hyp, self.policy.blob, self.q_funcs.blob, b[0], b[1], self._stats, self._ws,
-                          policy_ready=self._policy_rides_along())
+                          policy_ready=self._policy_rides_along(), actor_blob_T=self.policy.blob_T, q_blob_T=self.q_funcs.blob_T)
 
     def stats_buffer(self):
         return self._stats

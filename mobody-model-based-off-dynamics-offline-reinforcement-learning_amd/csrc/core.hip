@@ -140,6 +140,8 @@ extern "C" int mobody_mlp_layout(int in_dim, int out_dim, int members, MobodyMlp
   out->w3t = t; t += (int64_t)out->Np3 * HID;
   out->w2t = t; t += (int64_t)HID * HID;
   out->w1t = t; t += (int64_t)HID * out->Np1t;
+  out->w2p = t; t += 3 * (int64_t)HID * HID / 2;        // three bf16 planes of W2 (2 bf16 per float slot)
+  out->w2tp = t; t += 3 * (int64_t)HID * HID / 2;       // ... and of W2^T
   out->t_member_floats = t; out->t_total_floats = t * members;
   return 0;
 }

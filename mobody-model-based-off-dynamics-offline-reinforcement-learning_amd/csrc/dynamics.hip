@@ -15,7 +15,7 @@
 // S=17,A=6 against 240 algorithmic bytes); k_dyn_sample / k_dyn_finalize are HBM-bound
 // streaming kernels over [E,B,S] floats.
 #include "common.h"
-#include "layers.h"
+#include "layers_bf.h"
 #include "rng.h"
 
 namespace mobody {
@@ -28,13 +28,22 @@ struct DynFwdArgs {
   float* mean;        // [E][B][S]
   long long B;
   int use_trg;
+  const unsigned short* planes;   // split-precision modes: bf16 planes of zs2 | transition2 | reward_model2 (dyn_planes_off)
 };
 
+// bf16 planes of the three 256 x 256 ensemble layers: [layer 0..2 = zs2, transition2, reward_model2][member][3 planes][65536]
+constexpr long long DYN_PLANE_MEMBER = 3LL * HID * HID;                       // bf16 elements per (layer, member)
+__host__ __device__ inline long long dyn_planes_off(int layer, int member) { return ((long long)layer * NENS + member) * DYN_PLANE_MEMBER; }
+
 // NT3: 16-column tiles of the transition head handled by the K-split narrow layer (Np == 16*NT3), 0 = any width.
-template <int MT, int NT3>
+// NPL: 0 = exact fp32 MFMA; 1..3 = the two 256 x 256 layers (zs2, transition2) on the split-precision bf16 core.
+template <int MT, int NT3, int NPL>
 __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   constexpr int TB = 32 * MT;
+  __bf16* Ps = reinterpret_cast<__bf16*>(Xs);
+  constexpr int NPLX = NPL > 0 ? NPL : 1;
+  BfRing<NPLX> bring;
   const int e = blockIdx.y;
   const long long row0 = (long long)blockIdx.x * TB;
   const int rows_here = (int)min((long long)TB, a.B - row0);
@@ -50,9 +59,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   tile_load(Xs, 0, a.obs + row0 * S, S, S, 0, rows_here, TB);
   tile_zero_cols(Xs, S, a.L.layer[MOBODY_DL_ZS1].Kp, TB);
   lds_barrier();
-  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, ring, NoExtra{},
-                            [&] { wide_prefetch(Wp(MOBODY_DL_ZS2), HID, ring); });
-  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS2), Bp(MOBODY_DL_ZS2), HID, ring, NoExtra{}, [] {});
+  if constexpr (NPL > 0) {
+    const bf16x8* pz = reinterpret_cast<const bf16x8*>(a.planes + dyn_planes_off(0, e));
+    wide_layer_to_planes<ACT_SWISH, MT, NPLX>(Xs, Ps, TB, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, ring,
+                                              NoExtra{}, [&] { bf_prefetch<NPLX>(pz, bring); }, nullptr, false, 0);
+    bf_layer<ACT_SWISH, MT, NPLX>(Xs, Ps, TB, pz, Bp(MOBODY_DL_ZS2), bring, NoExtra{}, [] {}, nullptr, false, 0);
+  } else {
+    wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, ring, NoExtra{},
+                              [&] { wide_prefetch(Wp(MOBODY_DL_ZS2), HID, ring); });
+    wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS2), Bp(MOBODY_DL_ZS2), HID, ring, NoExtra{}, [] {});
+  }
 
   // From here to the latent sum every wave works on its own 16 rows: no barriers needed (waves without rows idle).
   if (16 * w < TB) {
@@ -95,15 +111,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
 
   // ---- transition decoder   (encode_transition :287-293) ----
   wide_prefetch(Wp(MOBODY_DL_TR1), 16, ring);
-  wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, ring, NoExtra{},
-                            [&] { wide_prefetch(Wp(MOBODY_DL_TR2), HID, ring); });
+  const bf16x8* pt = NPL > 0 ? reinterpret_cast<const bf16x8*>(a.planes + dyn_planes_off(1, e)) : nullptr;
+  if constexpr (NPL > 0)
+    wide_layer_to_planes<ACT_SWISH, MT, NPLX>(Xs, Ps, TB, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, ring, NoExtra{},
+                                              [&] { bf_prefetch<NPLX>(pt, bring); }, nullptr, false, 0);
+  else
+    wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, ring, NoExtra{},
+                              [&] { wide_prefetch(Wp(MOBODY_DL_TR2), HID, ring); });
   const float* b3 = Bp(MOBODY_DL_TR3);
   float* mean = a.mean + ((long long)e * a.B + row0) * S;
+  // transition2 at the requested precision; `between` runs after its last MFMA (the output layer's early requests)
+  auto layer_tr2 = [&](auto&& between) {
+    if constexpr (NPL > 0) bf_layer<ACT_SWISH, MT, NPLX>(Xs, Ps, TB, pt, Bp(MOBODY_DL_TR2), bring, NoExtra{}, between, nullptr, false, 0);
+    else wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, ring, NoExtra{}, between);
+  };
   if constexpr (NT3 > 0) {
     NarrowRegs<NT3> br;
     const int mycol = threadIdx.x % (16 * NT3);          // column of every output element this thread finishes
     float bias;
-    wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, ring, NoExtra{}, [&] {
+    layer_tr2([&] {
       narrow_prefetch<NT3>(Wp(MOBODY_DL_TR3), 16 * NT3, br);
       bias = b3[mycol < S ? mycol : 0];
     });
@@ -111,7 +137,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
       if (row < rows_here && col < S) mean[row * S + col] = v + bias;
     });
   } else {
-    wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, ring, NoExtra{}, [] {});
+    layer_tr2([] {});
     narrow_layer(Xs, Wp(MOBODY_DL_TR3), HID, a.L.layer[MOBODY_DL_TR3].Np, [&](int row, int col, float v) {
       if (row < rows_here && col < S) mean[row * S + col] = v + b3[col];
     }, TB);
@@ -244,46 +270,93 @@ __global__ __launch_bounds__(256) void k_dyn_finalize(DynFinalArgs a) {
   a.reward[b] = (a.coef != 0.f) ? raw - a.coef * a.penalty[b] : raw;       // :261-263
 }
 
-template <int MT, int NT3>
+template <int MT, int NT3, int NPL>
 static int launch_dyn_fwd_t(const DynFwdArgs& a, hipStream_t st) {
-  constexpr size_t lds = (size_t)32 * MT * LDX * sizeof(float);
+  constexpr size_t f32b = (size_t)32 * MT * LDX * sizeof(float), plb = (size_t)NPL * 32 * MT * LDP * sizeof(__bf16);
+  constexpr size_t lds = f32b > plb ? f32b : plb;
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_dyn_fwd<MT, NT3>, lds);
+    int rc = allow_big_lds(k_dyn_fwd<MT, NT3, NPL>, lds);
     if (rc) return rc;
     once = true;
   }
   ProfScope prof(PROF_DYN_FWD, st);
-  hipLaunchKernelGGL((k_dyn_fwd<MT, NT3>), dim3((unsigned)cdiv(a.B, 32 * MT), NENS), dim3(NTHREADS), lds, st, a);
+  hipLaunchKernelGGL((k_dyn_fwd<MT, NT3, NPL>), dim3((unsigned)cdiv(a.B, 32 * MT), NENS), dim3(NTHREADS), lds, st, a);
   MB_LAUNCH_OK("k_dyn_fwd");
   return 0;
 }
+template <int MT, int NPL>
+static int launch_dyn_fwd_nt(const DynFwdArgs& a, int nt3, hipStream_t st) {
+  return nt3 == 1 ? launch_dyn_fwd_t<MT, 1, NPL>(a, st) : nt3 == 2 ? launch_dyn_fwd_t<MT, 2, NPL>(a, st) : launch_dyn_fwd_t<MT, 0, NPL>(a, st);
+}
 
 static int launch_dyn_fwd(const float* blob, const MobodyDynLayout& L, const float* obs, const float* act, long long B,
-                          int use_trg, float* mean, hipStream_t st) {
-  DynFwdArgs a{blob, L, obs, act, mean, B, use_trg};
-  // 64-row tiles here: the nine-layer chain has a wave-local narrow section in which a 32-row tile idles half of
+                          int use_trg, float* mean, const float* planes, int prec, hipStream_t st) {
+  DynFwdArgs a{blob, L, obs, act, mean, B, use_trg, reinterpret_cast<const unsigned short*>(planes)};
+  // 64-row tiles for fp32: the nine-layer chain has a wave-local narrow section in which a 32-row tile idles half of
   // the waves (measured 102 vs 88 TFLOP/s at 50 000 rows); MOBODY_DYN_TILE_ROWS=32 selects the short tile.
-  static const bool short_tile = [] { const char* e = getenv("MOBODY_DYN_TILE_ROWS"); return e && atoi(e) == 32; }();
+  static const int forced = [] { const char* e = getenv("MOBODY_DYN_TILE_ROWS"); return e ? atoi(e) : 0; }();
   const int np = L.layer[MOBODY_DL_TR3].Np;
   const int nt3 = np == 16 ? 1 : np == 32 ? 2 : 0;
-  if (short_tile) return nt3 == 1 ? launch_dyn_fwd_t<1, 1>(a, st) : nt3 == 2 ? launch_dyn_fwd_t<1, 2>(a, st) : launch_dyn_fwd_t<1, 0>(a, st);
-  return nt3 == 1 ? launch_dyn_fwd_t<2, 1>(a, st) : nt3 == 2 ? launch_dyn_fwd_t<2, 2>(a, st) : launch_dyn_fwd_t<2, 0>(a, st);
+  if (prec == 0) return forced == 32 ? launch_dyn_fwd_nt<1, 0>(a, nt3, st) : launch_dyn_fwd_nt<2, 0>(a, nt3, st);
+  // split-precision modes: the planes of a 64-row tile are 34 / 68 / 101 KB for 1 / 2 / 3 terms -> the three-term mode
+  // runs 32-row tiles (51 KB, three workgroups per CU)
+  const bool tall = forced == 64 || (forced != 32 && prec <= 2);
+  if (prec == 1) return tall ? launch_dyn_fwd_nt<2, 1>(a, nt3, st) : launch_dyn_fwd_nt<1, 1>(a, nt3, st);
+  if (prec == 2) return tall ? launch_dyn_fwd_nt<2, 2>(a, nt3, st) : launch_dyn_fwd_nt<1, 2>(a, nt3, st);
+  return tall ? launch_dyn_fwd_nt<2, 3>(a, nt3, st) : launch_dyn_fwd_nt<1, 3>(a, nt3, st);
+}
+
+// zs2 / transition2 / reward_model2 of every member -> their three bf16 planes
+__global__ __launch_bounds__(256) void k_dyn_planes(const float* blob, MobodyDynLayout L, __bf16* planes) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= 3LL * NENS * HID * HID) return;
+  const int layer = (int)(gid / ((long long)NENS * HID * HID));
+  const long long rem = gid - (long long)layer * NENS * HID * HID;
+  const int e = (int)(rem / (HID * HID)), el = (int)(rem % (HID * HID)), k = el / HID, n = el % HID;
+  const int li = layer == 0 ? MOBODY_DL_ZS2 : layer == 1 ? MOBODY_DL_TR2 : MOBODY_DL_RW2;
+  const float w = blob[L.layer[li].w_off + (long long)e * HID * HID + wide_idx(k, n)];
+  __bf16 t[3];
+  bf_split<3>(w, t);
+  __bf16* pl = planes + dyn_planes_off(layer, e);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) pl[bf_plane_idx(p, k, n)] = t[p];
 }
 
 }  // namespace mobody
 
 using namespace mobody;
 
-extern "C" int mobody_dyn_forward(const float* dyn_blob, int S, int A, const float* obs, const float* act, int64_t B,
-                                  int use_trg, float* mean, void* stream) {
+extern "C" int64_t mobody_dyn_planes_floats(void) { return 3LL * NENS * DYN_PLANE_MEMBER / 2; }
+
+extern "C" int mobody_dyn_planes(const float* dyn_blob, int S, int A, float* planes, void* stream) {
+  MobodyDynLayout L;
+  int rc = mobody_dyn_layout(S, A, &L);
+  if (rc) return rc;
+  MB_REQUIRE(dyn_blob && planes, "mobody_dyn_planes: null pointer");
+  hipLaunchKernelGGL(k_dyn_planes, dim3((unsigned)cdiv(3LL * NENS * HID * HID, 256)), dim3(256), 0, as_stream(stream), dyn_blob, L,
+                     reinterpret_cast<__bf16*>(planes));
+  MB_LAUNCH_OK("k_dyn_planes");
+  return 0;
+}
+
+static int check_dyn_prec(const char* who, int precision, const float* planes) {
+  MB_REQUIRE(precision >= 0 && precision <= 3, "%s: precision must be 0 (f32), 1 (bf16), 2 (bf16x2) or 3 (bf16x3)", who);
+  MB_REQUIRE(precision == 0 || planes, "%s: the split-precision modes need the plane blob (mobody_dyn_planes)", who);
+  return 0;
+}
+
+extern "C" int mobody_dyn_forward(const float* dyn_blob, const float* dyn_planes, int precision, int S, int A, const float* obs,
+                                  const float* act, int64_t B, int use_trg, float* mean, void* stream) {
   MobodyDynLayout L;
   int rc = mobody_dyn_layout(S, A, &L);
   if (rc) return rc;
   MB_REQUIRE(B >= 0, "mobody_dyn_forward: B < 0");
   if (B == 0) return 0;                      // empty batch: nothing to do (pointers may be null)
   MB_REQUIRE(dyn_blob && obs && act && mean, "mobody_dyn_forward: null pointer");
-  return launch_dyn_fwd(dyn_blob, L, obs, act, B, use_trg, mean, as_stream(stream));
+  rc = check_dyn_prec("mobody_dyn_forward", precision, dyn_planes);
+  if (rc) return rc;
+  return launch_dyn_fwd(dyn_blob, L, obs, act, B, use_trg, mean, dyn_planes, precision, as_stream(stream));
 }
 
 extern "C" int64_t mobody_dyn_step_workspace(int S, int A, int64_t B) {
@@ -291,7 +364,7 @@ extern "C" int64_t mobody_dyn_step_workspace(int S, int A, int64_t B) {
   return (int64_t)NENS * B * S + (int64_t)NENS * B;    // ensemble means + per-member reward means
 }
 
-static int dyn_step_impl(const float* dyn_blob, int S, int A, int task, const float* obs, const float* act,
+static int dyn_step_impl(const float* dyn_blob, const float* dyn_planes, int precision, int S, int A, int task, const float* obs, const float* act,
                          int64_t B, const float* noise, const int32_t* elite_idx, const uint8_t* alive,
                          const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty,
                          int use_trg, float* next_obs, float* reward, uint8_t* terminal, float* penalty,
@@ -310,7 +383,9 @@ static int dyn_step_impl(const float* dyn_blob, int S, int A, int task, const fl
   hipStream_t st = as_stream(stream);
   float* mean = mean_out ? mean_out : workspace;
   float* r_mu = workspace + (int64_t)NENS * B * S;
-  rc = launch_dyn_fwd(dyn_blob, L, obs, act, B, use_trg, mean, st);
+  rc = check_dyn_prec("mobody_dyn_step", precision, dyn_planes);
+  if (rc) return rc;
+  rc = launch_dyn_fwd(dyn_blob, L, obs, act, B, use_trg, mean, dyn_planes, precision, st);
   if (rc) return rc;
 
   DynSampleArgs sa{};
@@ -335,7 +410,13 @@ static int dyn_step_impl(const float* dyn_blob, int S, int A, int task, const fl
   m.Kp1 = l1.Kp; m.Np3 = l3.Np; m.nout = 1; m.rows = B;
   m.out = r_mu; m.out_mstride = B; m.out_ld = 1;
   m.out_mode = 0; m.max_action = 1.f;
-  rc = launch_mlp3_fwd(m, NENS, ACT_SWISH, st);
+  if (precision == 0) {
+    rc = launch_mlp3_fwd(m, NENS, ACT_SWISH, st);
+  } else {
+    m.w2_planes = reinterpret_cast<const unsigned short*>(dyn_planes) + dyn_planes_off(2, 0);
+    m.planes_ms = DYN_PLANE_MEMBER;
+    rc = launch_mlp3_fwd_bf(m, NENS, Mlp3FwdArgs{}, 0, ACT_SWISH, precision, st);
+  }
   if (rc) return rc;
 
   DynFinalArgs fa{r_mu, penalty, reward, raw_reward, B, (penalty_coef != 0.f && use_penalty) ? penalty_coef : 0.f};
@@ -344,12 +425,13 @@ static int dyn_step_impl(const float* dyn_blob, int S, int A, int task, const fl
   return 0;
 }
 
-extern "C" int mobody_dyn_step(const float* dyn_blob, int S, int A, int task, const float* obs, const float* act,
+extern "C" int mobody_dyn_step(const float* dyn_blob, const float* dyn_planes, int precision, int S, int A, int task,
+                               const float* obs, const float* act,
                                int64_t B, const float* noise, const int32_t* elite_idx, const uint8_t* alive,
                                const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty,
                                int use_trg, float* next_obs, float* reward, uint8_t* terminal, float* penalty,
                                float* raw_reward, float* mean_out, float* workspace, void* stream) {
-  return dyn_step_impl(dyn_blob, S, A, task, obs, act, B, noise, elite_idx, alive, elites, n_elites, seed, call, penalty_coef,
+  return dyn_step_impl(dyn_blob, dyn_planes, precision, S, A, task, obs, act, B, noise, elite_idx, alive, elites, n_elites, seed, call, penalty_coef,
                        use_penalty, use_trg, next_obs, reward, terminal, penalty, raw_reward, mean_out, workspace, nullptr, nullptr,
                        0.f, 0, stream);
 }
@@ -379,7 +461,8 @@ extern "C" int64_t mobody_rollout_workspace(int S, int A, int64_t B) {
   return w.total;
 }
 
-extern "C" int mobody_rollout(const float* dyn_blob, const float* actor_blob, int S, int A, int task, float max_action,
+extern "C" int mobody_rollout(const float* dyn_blob, const float* dyn_planes, const float* actor_blob, const float* actor_blob_T,
+                              int precision, int S, int A, int task, float max_action,
                               const float* init_obs, int64_t B, int H, const int32_t* elites, int n_elites, uint32_t seed,
                               uint32_t call0, float penalty_coef, int use_penalty, int use_trg, float env_filter,
                               int filter_bad_rollout, float* b_state, float* b_action, float* b_next_state, float* b_reward,
@@ -406,11 +489,18 @@ extern "C" int mobody_rollout(const float* dyn_blob, const float* actor_blob, in
     p.sw1 = p.sb1 = p.sw2 = p.sb2 = p.sw3 = p.sb3 = La.member_floats;
     p.Kp1 = La.Kp1; p.Np3 = La.Np3; p.nout = A; p.rows = B; p.out = w.act; p.out_mstride = B * A; p.out_ld = A;
     p.out_mode = 1; p.max_action = max_action;
-    rc = launch_mlp3_fwd(p, 1, ACT_RELU, st);
+    if (precision == 0) {
+      rc = launch_mlp3_fwd(p, 1, ACT_RELU, st);
+    } else {
+      MB_REQUIRE(actor_blob_T, "mobody_rollout: the split-precision modes need the actor's T blob");
+      p.w2_planes = reinterpret_cast<const unsigned short*>(actor_blob_T + La.w2p);
+      p.planes_ms = 2 * La.t_member_floats;
+      rc = launch_mlp3_fwd_bf(p, 1, Mlp3FwdArgs{}, 0, ACT_RELU, precision, st);
+    }
     if (rc) return rc;
     // one imagined transition for every row; rows that terminated earlier keep their index and are flagged (alive mask);
     // the penalty filter and the alive update are formed in the sample kernel
-    rc = dyn_step_impl(dyn_blob, S, A, task, obs, w.act, B, nullptr, nullptr, t == 0 ? nullptr : w.alive, elites, n_elites, seed,
+    rc = dyn_step_impl(dyn_blob, dyn_planes, precision, S, A, task, obs, w.act, B, nullptr, nullptr, t == 0 ? nullptr : w.alive, elites, n_elites, seed,
                        call0 + (uint32_t)t, penalty_coef, use_penalty, use_trg, nxt, w.reward, w.terminal, w.penalty, nullptr, nullptr,
                        w.dyn, w.keep, w.alive, env_filter, filter_bad_rollout, stream);
     if (rc) return rc;

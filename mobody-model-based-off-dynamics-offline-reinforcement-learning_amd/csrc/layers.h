@@ -124,6 +124,8 @@ struct Mlp3FwdArgs {
   float* save_h2;
   uint32_t* mask1;          // [members][ceil(rows/32)][256] sign bits of h1 / h2 (optional, see wide_layer)
   uint32_t* mask2;
+  const unsigned short* w2_planes;   // split-precision modes: bf16 planes of W2, member 0 ([3][32][256][8] bf16 per member, tile_bf.h)
+  long long planes_ms;               // member stride of w2_planes in bf16 elements
   float* save_d1;           // [members][rows][256] Swish derivative at the pre-activations of layers 1 / 2 (training
   float* save_d2;           // forward of the ensemble nets only: k_mlp3_fwd_train)
   int out_mode;             // 0 raw, 1 max_action*tanh
@@ -132,6 +134,8 @@ struct Mlp3FwdArgs {
 
 int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stream);
 int launch_mlp3_fwd_pair(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, hipStream_t stream);
+// split-precision forward (mlp_fwd_bf.hip): prec 1 bf16 / 2 bf16x2 / 3 bf16x3; needs a.w2_planes (and b.w2_planes)
+int launch_mlp3_fwd_bf(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, int act, int prec, hipStream_t st);
 
 // Row-tile height of the fused MLP kernels.  Measured on MI355X (bench.py, S=17/A=6): 32-row tiles (33 KB LDS,
 // ~124 VGPRs -> 4 workgroups = 16 waves per CU) beat 64-row tiles (2 workgroups per CU) at every batch size from

@@ -190,9 +190,10 @@ int launch_mlp3_fwd(const Mlp3FwdArgs& a, int members, int act, hipStream_t stre
 
 using namespace mobody;
 
-extern "C" int mobody_mlp3_forward(const float* blob, int in_dim, int out_dim, int members, const float* src0, int n0,
-                                   const float* src1, int n1, int64_t rows, int out_mode, float max_action, float* out,
-                                   float* save_x, float* save_h1, float* save_h2, void* stream) {
+extern "C" int mobody_mlp3_forward(const float* blob, const float* blob_T, int precision, int in_dim, int out_dim,
+                                   int members, const float* src0, int n0, const float* src1, int n1, int64_t rows,
+                                   int out_mode, float max_action, float* out, float* save_x, float* save_h1,
+                                   float* save_h2, void* stream) {
   MobodyMlpLayout L;
   int rc = mobody_mlp_layout(in_dim, out_dim, members, &L);
   if (rc) return rc;
@@ -210,5 +211,9 @@ extern "C" int mobody_mlp3_forward(const float* blob, int in_dim, int out_dim, i
   a.out = out; a.out_mstride = rows * out_dim; a.out_ld = out_dim;
   a.save_x = save_x; a.save_h1 = save_h1; a.save_h2 = save_h2;
   a.out_mode = out_mode; a.max_action = max_action;
-  return launch_mlp3_fwd(a, members, ACT_RELU, as_stream(stream));
+  MB_REQUIRE(precision >= 0 && precision <= 3 && (precision == 0 || blob_T), "mobody_mlp3_forward: precision %d needs the T blob", precision);
+  if (precision == 0) return launch_mlp3_fwd(a, members, ACT_RELU, as_stream(stream));
+  a.w2_planes = reinterpret_cast<const unsigned short*>(blob_T + L.w2p);
+  a.planes_ms = 2 * L.t_member_floats;
+  return launch_mlp3_fwd_bf(a, members, Mlp3FwdArgs{}, 0, ACT_RELU, precision, as_stream(stream));
 }

@@ -857,7 +857,7 @@ extern "C" int mobody_dyn_validate(const float* dyn_blob, int S, int A, const fl
   MB_REQUIRE(dyn_blob && obs && act && next_obs && rew && out && workspace, "mobody_dyn_validate: null pointer");
   float* mean = workspace;
   float* r_mu = workspace + (int64_t)NENS * B * S;
-  rc = mobody_dyn_forward(dyn_blob, S, A, obs, act, B, use_trg, mean, stream);       // inference mode: z = mu (:1126-1129)
+  rc = mobody_dyn_forward(dyn_blob, nullptr, 0, S, A, obs, act, B, use_trg, mean, stream);       // inference mode: z = mu (:1126-1129), exact fp32
   if (rc) return rc;
   // reward head of member e on [s, a, mean_e]   (:1137: encode_reward(obs.repeat(7), act.repeat(7), mean))
   Mlp3FwdArgs m{};

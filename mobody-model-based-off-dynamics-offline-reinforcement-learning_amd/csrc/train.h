@@ -4,6 +4,7 @@
 
 #include "common.h"
 #include "tile.h"
+#include "tile_bf.h"
 
 namespace mobody {
 
@@ -87,6 +88,16 @@ int launch_wgrad(WgradArgs a, hipStream_t st);
 // on the host and rounded to fp32 once, as torch does when it multiplies a fp32 tensor by a Python float.
 struct AdamConsts { float w1, b2, w2, step_size, bc2_sqrt, eps, tau, one_minus_tau, gscale; };
 
+// W2[k][n] = w -> the three bf16 terms of w in the planes of W2 (as B[k][n]) and of W2^T (as B[n][k]) of a member's T blob
+__device__ __forceinline__ void write_w2_planes(float* t_member, const MobodyMlpLayout& L, int k, int n, float w) {
+  __bf16 t[3];
+  bf_split<3>(w, t);
+  __bf16* p2 = reinterpret_cast<__bf16*>(t_member + L.w2p);
+  __bf16* p2t = reinterpret_cast<__bf16*>(t_member + L.w2tp);
+#pragma unroll
+  for (int p = 0; p < 3; ++p) { p2[bf_plane_idx(p, k, n)] = t[p]; p2t[bf_plane_idx(p, n, k)] = t[p]; }
+}
+
 // Destination of parameter entry (member-local offset o) inside the member's T blob, or -1 (biases, padding rows).
 __device__ __forceinline__ long long t_blob_index(const MobodyMlpLayout& L, long long o) {
   if (o < L.b1) {                                   // W1 (wide storage): W1T[n][k] row major, ld = Np1t
@@ -112,6 +123,7 @@ __device__ __forceinline__ long long t_blob_index(const MobodyMlpLayout& L, long
 // gradient round trip through HBM fewer per network and step).
 struct AdamTarget {
   float *p, *m, *v, *target, *blob_T;       // target / blob_T may be null
+  float* target_T;                          // T blob of the target net (its W2 planes follow the Polyak update); may be null
   AdamConsts c;
   const long long* t_dev;                   // device step count (graph replay) or null
   float lr;
@@ -151,11 +163,19 @@ __device__ __forceinline__ void adam_element(const AdamTarget& a, const MobodyMl
   a.m[j] = mj; a.v[j] = vj;
   const float pj = a.p[j] - c.step_size * (mj / (sqrtf(vj) / c.bc2_sqrt + c.eps));
   a.p[j] = pj;
-  if (a.target != nullptr) a.target[j] = c.tau * pj + c.one_minus_tau * a.target[j];      // update_target :183-187
-  if (a.blob_T != nullptr) {                        // keep the transposes the backward kernels stream in sync
+  float tj = 0.f;
+  if (a.target != nullptr) { tj = c.tau * pj + c.one_minus_tau * a.target[j]; a.target[j] = tj; }      // update_target :183-187
+  if (a.blob_T != nullptr || a.target_T != nullptr) {   // keep the transposes / bf16 planes the kernels stream in sync
     const int mem = (int)(j / L.member_floats);
-    const long long ti = t_blob_index(L, j - (long long)mem * L.member_floats);
-    if (ti >= 0) a.blob_T[(long long)mem * L.t_member_floats + ti] = pj;
+    const long long o = j - (long long)mem * L.member_floats;
+    const long long ti = t_blob_index(L, o);
+    if (ti >= 0 && a.blob_T != nullptr) a.blob_T[(long long)mem * L.t_member_floats + ti] = pj;
+    if (o >= L.w2 && o < L.b2) {                     // a W2 element (wide storage): its planes
+      const long long oo = o - L.w2, g = oo >> 2;
+      const int k = (int)(g / HID) * 4 + (int)(oo & 3), n = (int)(g % HID);
+      if (a.blob_T != nullptr) write_w2_planes(a.blob_T + (long long)mem * L.t_member_floats, L, k, n, pj);
+      if (a.target_T != nullptr && a.target != nullptr) write_w2_planes(a.target_T + (long long)mem * L.t_member_floats, L, k, n, tj);
+    }
   }
 }
 

@@ -167,6 +167,12 @@ __global__ __launch_bounds__(256) void k_mlp_transpose(MobodyMlpLayout L, const 
   const int m = (int)(j / L.t_member_floats);
   const long long o = j - (long long)m * L.t_member_floats;
   const float* src = blob + (long long)m * L.member_floats;
+  if (o >= L.w2p) {                                // bf16 planes of W2 / W2^T: one thread per float slot writes nothing here;
+    if (o >= L.w2p + HID * HID) return;            // the first 65536 threads of the region each split one weight
+    const int e = (int)(o - L.w2p), k = e / HID, n = e % HID;
+    write_w2_planes(bt + (long long)m * L.t_member_floats, L, k, n, src[L.w2 + wide_idx(k, n)]);
+    return;
+  }
   float val;
   if (o < L.w1t) {                               // wide regions of the T blob: decode (row kk, column c) of storage slot o
     const bool is3 = o < L.w2t;
@@ -188,8 +194,12 @@ __global__ __launch_bounds__(256) void k_mlp_transpose(MobodyMlpLayout L, const 
 // ------------------------------------------------------------------------------------------------
 static Mlp3FwdArgs fwd_args(const float* blob, const MobodyMlpLayout& L, const float* s0, int n0, const float* s1, int n1,
                             long long rows, float* out, int out_mode, float max_action, float* sx, float* sh1,
-                            float* sh2, uint32_t* m1 = nullptr, uint32_t* m2 = nullptr) {
+                            float* sh2, uint32_t* m1 = nullptr, uint32_t* m2 = nullptr, const float* blob_T = nullptr) {
   Mlp3FwdArgs a{};
+  if (blob_T != nullptr) {                          // split-precision modes stream W2's bf16 planes from the T blob
+    a.w2_planes = reinterpret_cast<const unsigned short*>(blob_T + L.w2p);
+    a.planes_ms = 2 * L.t_member_floats;
+  }
   a.src[0] = s0; a.ld[0] = n0; a.n[0] = n0;
   a.src[1] = s1; a.ld[1] = n1; a.n[1] = s1 ? n1 : 0;
   a.w1 = blob + L.w1; a.b1 = blob + L.b1; a.w2 = blob + L.w2; a.b2 = blob + L.b2; a.w3 = blob + L.w3; a.b3 = blob + L.b3;
@@ -199,6 +209,24 @@ static Mlp3FwdArgs fwd_args(const float* blob, const MobodyMlpLayout& L, const f
   a.save_x = sx; a.save_h1 = sh1; a.save_h2 = sh2; a.mask1 = m1; a.mask2 = m2;
   a.out_mode = out_mode; a.max_action = max_action;
   return a;
+}
+
+// two ReLU nets in one launch at the requested precision (0 = exact fp32 MFMA)
+static int fwd_pair(const Mlp3FwdArgs& a, int ma, const Mlp3FwdArgs& b, int mb, int prec, hipStream_t st) {
+  if (prec == 0) return launch_mlp3_fwd_pair(a, ma, b, mb, st);
+  if (a.rows > 0 && b.rows > 0 && a.Np3 != b.Np3) {   // the merged kernel is specialised on one output-layer width
+    int rc = launch_mlp3_fwd_bf(a, ma, Mlp3FwdArgs{}, 0, ACT_RELU, prec, st);
+    return rc ? rc : launch_mlp3_fwd_bf(b, mb, Mlp3FwdArgs{}, 0, ACT_RELU, prec, st);
+  }
+  return launch_mlp3_fwd_bf(a, ma, b, mb, ACT_RELU, prec, st);
+}
+static int fwd_one(const Mlp3FwdArgs& a, int ma, int prec, hipStream_t st) {
+  return prec == 0 ? launch_mlp3_fwd(a, ma, ACT_RELU, st) : launch_mlp3_fwd_bf(a, ma, Mlp3FwdArgs{}, 0, ACT_RELU, prec, st);
+}
+static int check_prec(const MobodyHyper* h, const char* who, bool have_planes) {
+  MB_REQUIRE(h->precision >= 0 && h->precision <= 3, "%s: precision must be 0 (f32), 1 (bf16), 2 (bf16x2) or 3 (bf16x3)", who);
+  MB_REQUIRE(h->precision == 0 || have_planes, "%s: the split-precision modes need the T blobs (bf16 planes) of every net", who);
+  return 0;
 }
 
 // weight gradients of one packed MLP: one merged split-K launch + the deterministic reduction
@@ -233,8 +261,9 @@ extern "C" int64_t mobody_train_workspace(const MobodyTrainDims* d) {
 static AdamTarget adam_target(float* blob, float* blob_T, float* m, float* v, float* target, int64_t t, const int64_t* t_dev,
                               float lr, float tau, float grad_scale);
 
-static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* q_blob,
-                       const float* q_blob_T, const float* qtarg_blob, const float* state, const float* action,
+static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* actor_blob_T,
+                       const float* q_blob, const float* q_blob_T, const float* qtarg_blob, const float* qtarg_blob_T,
+                       const float* state, const float* action,
                        const float* next_state, const float* reward, const float* not_done, const float* q_next,
                        float* grad_q, const AdamTarget& adam, float* loss_out, float* workspace, int policy_forward,
                        void* stream) {
@@ -243,6 +272,10 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
   MB_REQUIRE(h && q_blob && q_blob_T && state && action && reward && not_done && (grad_q || adam.on) && loss_out && workspace,
              "mobody_critic_step: null pointer");
   MB_REQUIRE(q_next || (actor_blob && qtarg_blob && next_state), "mobody_critic_step: need q_next or actor/target/next_state");
+  rc = check_prec(h, "mobody_critic_step", q_next != nullptr || (actor_blob_T && qtarg_blob_T));
+  if (rc) return rc;
+  const int prec = h->precision;
+  const float *aT = prec ? actor_blob_T : nullptr, *qT = prec ? q_blob_T : nullptr, *tT = prec ? qtarg_blob_T : nullptr;
   TrainWs w;
   rc = carve(*d, workspace, w);
   if (rc) return rc;
@@ -250,19 +283,19 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
   const long long N = d->N;
   const int S = d->S, A = d->A;
   // online twin-Q(s, a), activations kept for the backward (:196), together with a' = pi(s') (:191) in one launch
-  const Mlp3FwdArgs fq = fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q, w.mq1, w.mq2);
+  const Mlp3FwdArgs fq = fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q, w.mq1, w.mq2, qT);
   if (q_next == nullptr) {
-    rc = launch_mlp3_fwd_pair(fq, 2, fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pin, 1, h->max_action, nullptr, nullptr, nullptr), 1, st);
+    rc = fwd_pair(fq, 2, fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pin, 1, h->max_action, nullptr, nullptr, nullptr, nullptr, nullptr, aT), 1, prec, st);
     // target twin-Q(s', a') (:192) -- and, when the caller asks for it, pi(s) of the coming actor phase in the same
     // launch: the actor is not updated in between, and a twin-Q launch alone is 2.5 workgroups per CU where the
     // merged one is 3.75 (the actor phase then opens with Q(s_t,a_t) alone: exactly 2 per CU)
-    const Mlp3FwdArgs ft = fwd_args(qtarg_blob, w.Lq, next_state, S, w.pin, A, N, w.qt, 0, 1.f, nullptr, nullptr, nullptr);
+    const Mlp3FwdArgs ft = fwd_args(qtarg_blob, w.Lq, next_state, S, w.pin, A, N, w.qt, 0, 1.f, nullptr, nullptr, nullptr, nullptr, nullptr, tT);
     if (!rc && policy_forward)
-      rc = launch_mlp3_fwd_pair(ft, 2, fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2), 1, st);
+      rc = fwd_pair(ft, 2, fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2, aT), 1, prec, st);
     else if (!rc)
-      rc = launch_mlp3_fwd(ft, 2, ACT_RELU, st);
+      rc = fwd_one(ft, 2, prec, st);
   } else {
-    rc = launch_mlp3_fwd(fq, 2, ACT_RELU, st);     // q_next = V(s') supplied by the caller (update_q_functions_1, :210-229)
+    rc = fwd_one(fq, 2, prec, st);                  // q_next = V(s') supplied by the caller (update_q_functions_1, :210-229)
   }
   if (rc) return rc;
   const float invNg = 1.f / (float)d->N_global;
@@ -278,33 +311,41 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
 }
 
 extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
-                                  const float* q_blob, const float* q_blob_T, const float* qtarg_blob,
-                                  const float* state, const float* action, const float* next_state,
-                                  const float* reward, const float* not_done, const float* q_next, float* grad_q,
-                                  float* loss_out, float* workspace, int policy_forward, void* stream) {
+                                  const float* actor_blob_T, const float* q_blob, const float* q_blob_T,
+                                  const float* qtarg_blob, const float* qtarg_blob_T, const float* state,
+                                  const float* action, const float* next_state, const float* reward, const float* not_done,
+                                  const float* q_next, float* grad_q, float* loss_out, float* workspace, int policy_forward,
+                                  void* stream) {
   MB_REQUIRE(grad_q, "mobody_critic_step: grad_q is null");
-  return critic_impl(d, h, actor_blob, q_blob, q_blob_T, qtarg_blob, state, action, next_state, reward, not_done, q_next,
-                     grad_q, AdamTarget{}, loss_out, workspace, policy_forward, stream);
+  return critic_impl(d, h, actor_blob, actor_blob_T, q_blob, q_blob_T, qtarg_blob, qtarg_blob_T, state, action, next_state, reward,
+                     not_done, q_next, grad_q, AdamTarget{}, loss_out, workspace, policy_forward, stream);
 }
 
-extern "C" int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, float* q_blob,
-                                    float* q_blob_T, float* qtarg_blob, const float* state, const float* action,
-                                    const float* next_state, const float* reward, const float* not_done,
-                                    const float* q_next, float* m, float* v, int64_t t, const int64_t* t_dev, float lr,
-                                    float* loss_out, float* workspace, int policy_forward, void* stream) {
+extern "C" int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
+                                    const float* actor_blob_T, float* q_blob, float* q_blob_T, float* qtarg_blob,
+                                    float* qtarg_blob_T, const float* state, const float* action, const float* next_state,
+                                    const float* reward, const float* not_done, const float* q_next, float* m, float* v,
+                                    int64_t t, const int64_t* t_dev, float lr, float* loss_out, float* workspace,
+                                    int policy_forward, void* stream) {
   MB_REQUIRE(h && q_blob && q_blob_T && qtarg_blob && m && v, "mobody_critic_update: null pointer");
   MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_critic_update: step t must be >= 1");
-  return critic_impl(d, h, actor_blob, q_blob, q_blob_T, qtarg_blob, state, action, next_state, reward, not_done, q_next,
-                     nullptr, adam_target(q_blob, q_blob_T, m, v, qtarg_blob, t, t_dev, lr, h->tau, 1.f), loss_out,
-                     workspace, policy_forward, stream);
+  AdamTarget at = adam_target(q_blob, q_blob_T, m, v, qtarg_blob, t, t_dev, lr, h->tau, 1.f);
+  at.target_T = qtarg_blob_T;
+  return critic_impl(d, h, actor_blob, actor_blob_T, q_blob, q_blob_T, qtarg_blob, qtarg_blob_T, state, action, next_state, reward,
+                     not_done, q_next, nullptr, at, loss_out, workspace, policy_forward, stream);
 }
 
 extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
-                                    const float* q_blob, const float* state, const float* action, float* stats,
-                                    float* workspace, int policy_ready, void* stream) {
+                                    const float* actor_blob_T, const float* q_blob, const float* q_blob_T,
+                                    const float* state, const float* action, float* stats, float* workspace, int policy_ready,
+                                    void* stream) {
   int rc = check_dims(d, "mobody_actor_forward");
   if (rc) return rc;
   MB_REQUIRE(h && actor_blob && q_blob && state && action && stats && workspace, "mobody_actor_forward: null pointer");
+  rc = check_prec(h, "mobody_actor_forward", actor_blob_T && q_blob_T);
+  if (rc) return rc;
+  const int prec = h->precision;
+  const float *aT = prec ? actor_blob_T : nullptr, *qT = prec ? q_blob_T : nullptr;
   TrainWs w;
   rc = carve(*d, workspace, w);
   if (rc) return rc;
@@ -313,18 +354,18 @@ extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper*
   const int S = d->S, A = d->A;
   // Q(s_true, a_true) for the BC weights (:251) and pi(s) on the whole mixed batch (its first Nt rows are
   // pi(s_true), mobody.py:249,315) in one launch -- unless the critic call already left pi(s) in the workspace
-  const Mlp3FwdArgs fb = fwd_args(q_blob, w.Lq, state, S, action, A, Nt, w.qb, 0, 1.f, nullptr, nullptr, nullptr);
+  const Mlp3FwdArgs fb = fwd_args(q_blob, w.Lq, state, S, action, A, Nt, w.qb, 0, 1.f, nullptr, nullptr, nullptr, nullptr, nullptr, qT);
   // Q(s, pi(s)) with the freshly updated critic (:316); dQ/da through the frozen net needs only the ReLU signs
-  const Mlp3FwdArgs fp = fwd_args(q_blob, w.Lq, state, S, w.pi, A, N, w.q, 0, 1.f, nullptr, nullptr, nullptr, w.mq1, w.mq2);
+  const Mlp3FwdArgs fp = fwd_args(q_blob, w.Lq, state, S, w.pi, A, N, w.q, 0, 1.f, nullptr, nullptr, nullptr, w.mq1, w.mq2, qT);
   static const bool split_q = [] { const char* e = getenv("MOBODY_MERGE_ACTOR_Q"); return e && atoi(e) == 0; }();   // tuning aid
   if (policy_ready && !split_q) {
-    rc = launch_mlp3_fwd_pair(fb, 2, fp, 2, st);           // both on the same critic: one launch of N + Nt rows (0.384 -> 0.380 ms/step)
+    rc = fwd_pair(fb, 2, fp, 2, prec, st);                 // both on the same critic: one launch of N + Nt rows (0.384 -> 0.380 ms/step)
   } else {
     if (policy_ready)
-      rc = launch_mlp3_fwd(fb, 2, ACT_RELU, st);
+      rc = fwd_one(fb, 2, prec, st);
     else
-      rc = launch_mlp3_fwd_pair(fb, 2, fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2), 1, st);
-    if (!rc) rc = launch_mlp3_fwd(fp, 2, ACT_RELU, st);
+      rc = fwd_pair(fb, 2, fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2, aT), 1, prec, st);
+    if (!rc) rc = fwd_one(fp, 2, prec, st);
   }
   if (rc) return rc;
   hipLaunchKernelGGL(k_actor_stats, dim3(1), dim3(1024), 0, st, w.q, w.qb, N, Nt, stats);
@@ -413,14 +454,15 @@ static AdamTarget adam_target(float* blob, float* blob_T, float* m, float* v, fl
 }
 
 static int adam_impl(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad, float* m,
-                     float* v, float* target, int64_t t, const int64_t* t_dev, float lr, float tau, float grad_scale,
-                     void* stream) {
+                     float* v, float* target, float* target_T, int64_t t, const int64_t* t_dev, float lr, float tau,
+                     float grad_scale, void* stream) {
   MobodyMlpLayout L;
   int rc = mobody_mlp_layout(in_dim, out_dim, members, &L);
   if (rc) return rc;
   MB_REQUIRE(blob && grad && m && v, "mobody_adam_polyak: null pointer");
   MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_adam_polyak: step t must be >= 1");
-  const AdamTarget a = adam_target(blob, blob_T, m, v, target, t, t_dev, lr, tau, grad_scale);
+  AdamTarget a = adam_target(blob, blob_T, m, v, target, t, t_dev, lr, tau, grad_scale);
+  a.target_T = a.target ? target_T : nullptr;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)cdiv(L.total_floats, 256)), dim3(256), 0, st, a, grad, (long long)L.total_floats, L);
   MB_LAUNCH_OK("k_adam");
@@ -428,16 +470,16 @@ static int adam_impl(int in_dim, int out_dim, int members, float* blob, float* b
 }
 
 extern "C" int mobody_adam_polyak(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad,
-                                  float* m, float* v, float* target, int64_t t, float lr, float tau, float grad_scale,
-                                  void* stream) {
-  return adam_impl(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t, nullptr, lr, tau, grad_scale, stream);
+                                  float* m, float* v, float* target, float* target_T, int64_t t, float lr, float tau,
+                                  float grad_scale, void* stream) {
+  return adam_impl(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, target_T, t, nullptr, lr, tau, grad_scale, stream);
 }
 
 extern "C" int mobody_adam_polyak_dev(int in_dim, int out_dim, int members, float* blob, float* blob_T,
-                                      const float* grad, float* m, float* v, float* target, const int64_t* t_dev,
-                                      float lr, float tau, float grad_scale, void* stream) {
+                                      const float* grad, float* m, float* v, float* target, float* target_T,
+                                      const int64_t* t_dev, float lr, float tau, float grad_scale, void* stream) {
   MB_REQUIRE(t_dev != nullptr, "mobody_adam_polyak_dev: t_dev is null");
-  return adam_impl(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, 0, t_dev, lr, tau, grad_scale, stream);
+  return adam_impl(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, target_T, 0, t_dev, lr, tau, grad_scale, stream);
 }
 
 // ---- PAR reward penalty: r -= coef * mean_d (s'_true - s'_model)^2   (mobody.py:428-434) ----

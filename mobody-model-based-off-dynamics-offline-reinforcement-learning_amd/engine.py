@@ -31,6 +31,7 @@ class Engine:
         self.qt = self.q.clone()
         self.actor_T = ops.mlp_transpose(self.actor, S, A, 1)
         self.q_T = ops.mlp_transpose(self.q, S + A, 1, 2)
+        self.qt_T = self.q_T.clone()                   # the target's T blob (its W2 planes follow the Polyak update)
         z = torch.zeros_like
         self.ma, self.va, self.mq, self.vq = z(self.actor), z(self.actor), z(self.q), z(self.q)
         self.ga, self.gq = z(self.actor), z(self.q)
@@ -46,11 +47,13 @@ class Engine:
         dims = dims or ops.train_dims(S, A, N, n_true)
         hyp = ops.hyper(cfg)
         ws = ops.train_workspace(dims, self.dev)
-        ops.critic_step(dims, hyp, self.actor, self.q, self.q_T, self.qt, b, self.gq, self.loss[0:1], ws)
+        ops.critic_step(dims, hyp, self.actor, self.q, self.q_T, self.qt, b, self.gq, self.loss[0:1], ws,
+                        actor_blob_T=self.actor_T, qtarg_blob_T=self.qt_T)
         if apply:
             self.t += 1
-            ops.adam_polyak(S + A, 1, 2, self.q, self.q_T, self.gq, self.mq, self.vq, self.qt, self.t, cfg["critic_lr"], cfg["tau"])
-        ops.actor_forward(dims, hyp, self.actor, self.q, b[0], b[1], self.stats, ws)
+            ops.adam_polyak(S + A, 1, 2, self.q, self.q_T, self.gq, self.mq, self.vq, self.qt, self.t, cfg["critic_lr"], cfg["tau"],
+                            target_T=self.qt_T)
+        ops.actor_forward(dims, hyp, self.actor, self.q, b[0], b[1], self.stats, ws, actor_blob_T=self.actor_T, q_blob_T=self.q_T)
         ops.actor_backward(dims, hyp, self.actor, self.actor_T, self.q, self.q_T, b[0], b[1], self.stats, self.ga,
                            self.loss[1:3], ws)
         if apply:

@@ -30,17 +30,30 @@ def rng_index(seed, stream_id, call, n, bound, device):
     return out
 
 
-def dyn_forward(blob, S, A, obs, act, use_trg=True):
+def prec_id(mfma):
+    """'f32' | 'bf16' | 'bf16x2' | 'bf16x3' (or the integer id) -> MobodyHyper.precision."""
+    return mfma if isinstance(mfma, int) else _lib.PRECISIONS[mfma]
+
+
+def dyn_planes(blob, S, A, out=None):
+    """bf16 planes of zs2 / transition2 / reward_model2 for the split-precision modes."""
+    pl = out if out is not None else torch.empty(load().mobody_dyn_planes_floats(), dtype=torch.float32, device=blob.device)
+    check(load().mobody_dyn_planes(ptr(blob), S, A, ptr(pl), cur_stream()), "mobody_dyn_planes")
+    return pl
+
+
+def dyn_forward(blob, S, A, obs, act, use_trg=True, planes=None, precision=0):
     obs, act = _f32(obs), _f32(act)
     B = obs.shape[0]
     mean = torch.empty(7, B, S, dtype=torch.float32, device=obs.device)
-    check(load().mobody_dyn_forward(ptr(blob), S, A, ptr(obs), ptr(act), B, int(use_trg), ptr(mean), cur_stream()),
-          "mobody_dyn_forward")
+    check(load().mobody_dyn_forward(ptr(blob), ptr(planes), prec_id(precision), S, A, ptr(obs), ptr(act), B, int(use_trg),
+                                    ptr(mean), cur_stream()), "mobody_dyn_forward")
     return mean
 
 
 def dyn_step(blob, S, A, task_id, obs, act, noise=None, elite_idx=None, alive=None, elites=(0, 1, 2, 3, 4), seed=0,
-             call=0, penalty_coef=0.0, use_penalty=True, use_trg=True, want_mean=False, workspace=None, out=None):
+             call=0, penalty_coef=0.0, use_penalty=True, use_trg=True, want_mean=False, workspace=None, out=None,
+             planes=None, precision=0):
     """Returns dict(next_obs[B,S], reward[B,1], terminal uint8[B,1], penalty[B,1], raw_reward[B,1], mean?)."""
     obs, act = _f32(obs), _f32(act)
     dev, B = obs.device, obs.shape[0]
@@ -62,7 +75,7 @@ def dyn_step(blob, S, A, task_id, obs, act, noise=None, elite_idx=None, alive=No
     raw = o["raw_reward"] if "raw_reward" in o else torch.empty(B, 1, dtype=torch.float32, device=dev)
     mean = torch.empty(7, B, S, dtype=torch.float32, device=dev) if want_mean else None
     el = (C.c_int32 * len(elites))(*[int(e) for e in elites])
-    check(load().mobody_dyn_step(ptr(blob), S, A, task_id, ptr(obs), ptr(act), B, ptr(noise), ptr(elite_idx),
+    check(load().mobody_dyn_step(ptr(blob), ptr(planes), prec_id(precision), S, A, task_id, ptr(obs), ptr(act), B, ptr(noise), ptr(elite_idx),
                                  ptr(alive), el, len(elites), seed, call, float(penalty_coef), int(bool(use_penalty)),
                                  int(bool(use_trg)), ptr(nxt), ptr(rew), ptr(term), ptr(pen), ptr(raw), ptr(mean),
                                  ptr(workspace), cur_stream()), "mobody_dyn_step")
@@ -72,7 +85,8 @@ def dyn_step(blob, S, A, task_id, obs, act, noise=None, elite_idx=None, alive=No
     return res
 
 
-def mlp3_forward(blob, in_dim, out_dim, members, src0, src1=None, out_mode=0, max_action=1.0, save=False):
+def mlp3_forward(blob, in_dim, out_dim, members, src0, src1=None, out_mode=0, max_action=1.0, save=False, blob_T=None,
+                 precision=0):
     """out[members, rows, out_dim] (+ saved (x, h1, h2) when save=True)."""
     src0 = _f32(src0)
     rows, n0 = src0.shape
@@ -88,7 +102,7 @@ def mlp3_forward(blob, in_dim, out_dim, members, src0, src1=None, out_mode=0, ma
         sx = torch.empty(rows, L.Kp1, dtype=torch.float32, device=dev)
         sh1 = torch.empty(members, rows, 256, dtype=torch.float32, device=dev)
         sh2 = torch.empty(members, rows, 256, dtype=torch.float32, device=dev)
-    check(load().mobody_mlp3_forward(ptr(blob), in_dim, out_dim, members, ptr(src0), n0, ptr(src1), n1, rows, out_mode,
+    check(load().mobody_mlp3_forward(ptr(blob), ptr(blob_T), prec_id(precision), in_dim, out_dim, members, ptr(src0), n0, ptr(src1), n1, rows, out_mode,
                                      float(max_action), ptr(out), ptr(sx), ptr(sh1), ptr(sh2), cur_stream()),
           "mobody_mlp3_forward")
     return (out, sx, sh1, sh2) if save else out
@@ -103,7 +117,8 @@ def train_dims(S, A, N, Nt, N_global=None, Nt_global=None):
 
 def hyper(cfg):
     return _lib.MobodyHyper(float(cfg["gamma"]), float(cfg["tau"]), float(cfg["max_action"]), float(cfg["weight"]),
-                            float(cfg["bc_coef"]), int(bool(cfg["q_weighted"])), int(bool(cfg["scale_Q"])))
+                            float(cfg["bc_coef"]), int(bool(cfg["q_weighted"])), int(bool(cfg["scale_Q"])),
+                            prec_id(cfg.get("mfma", "f32")))
 
 
 def train_workspace(dims, device):
@@ -122,15 +137,15 @@ def mlp_transpose(blob, in_dim, out_dim, members, out=None):
 
 
 def critic_step(dims, hyp, actor_blob, q_blob, q_blob_T, qtarg_blob, batch, grad_q, loss_out, ws, q_next=None,
-                policy_forward=False):
+                policy_forward=False, actor_blob_T=None, qtarg_blob_T=None):
     s, a, s2, r, nd = batch
-    check(load().mobody_critic_step(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(q_blob), ptr(q_blob_T),
-                                    ptr(qtarg_blob), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(q_next), ptr(grad_q),
+    check(load().mobody_critic_step(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(actor_blob_T), ptr(q_blob), ptr(q_blob_T),
+                                    ptr(qtarg_blob), ptr(qtarg_blob_T), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(q_next), ptr(grad_q),
                                     ptr(loss_out), ptr(ws), int(bool(policy_forward)), cur_stream()), "mobody_critic_step")
 
 
-def actor_forward(dims, hyp, actor_blob, q_blob, state, action, stats, ws, policy_ready=False):
-    check(load().mobody_actor_forward(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(q_blob), ptr(state),
+def actor_forward(dims, hyp, actor_blob, q_blob, state, action, stats, ws, policy_ready=False, actor_blob_T=None, q_blob_T=None):
+    check(load().mobody_actor_forward(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(actor_blob_T), ptr(q_blob), ptr(q_blob_T), ptr(state),
                                       ptr(action), ptr(stats), ptr(ws), int(bool(policy_ready)), cur_stream()),
           "mobody_actor_forward")
 
@@ -143,11 +158,11 @@ def actor_backward(dims, hyp, actor_blob, actor_blob_T, q_blob, q_blob_T, state,
 
 
 def critic_update(dims, hyp, actor_blob, q_blob, q_blob_T, qtarg_blob, batch, m, v, t, lr, loss_out, ws, q_next=None,
-                  t_dev=None, policy_forward=False):
+                  t_dev=None, policy_forward=False, actor_blob_T=None, qtarg_blob_T=None):
     """critic_step + Adam + Polyak in the fused single-GPU form (t: host step count, or t_dev: device int64[1])."""
     s, a, s2, r, nd = batch
-    check(load().mobody_critic_update(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(q_blob), ptr(q_blob_T),
-                                      ptr(qtarg_blob), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(q_next), ptr(m),
+    check(load().mobody_critic_update(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(actor_blob_T), ptr(q_blob), ptr(q_blob_T),
+                                      ptr(qtarg_blob), ptr(qtarg_blob_T), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(q_next), ptr(m),
                                       ptr(v), int(t), ptr(t_dev), float(lr), ptr(loss_out), ptr(ws),
                                       int(bool(policy_forward)), cur_stream()),
           "mobody_critic_update")
@@ -172,9 +187,9 @@ def value_loss_grad(qt, v, n_global):
     return dz3, loss
 
 
-def adam_polyak(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t, lr, tau=-1.0, grad_scale=1.0):
+def adam_polyak(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t, lr, tau=-1.0, grad_scale=1.0, target_T=None):
     check(load().mobody_adam_polyak(in_dim, out_dim, members, ptr(blob), ptr(blob_T), ptr(grad), ptr(m), ptr(v),
-                                    ptr(target), int(t), float(lr), float(tau), float(grad_scale), cur_stream()),
+                                    ptr(target), ptr(target_T), int(t), float(lr), float(tau), float(grad_scale), cur_stream()),
           "mobody_adam_polyak")
 
 
@@ -246,9 +261,10 @@ def par_penalty(next_state_true, next_state_model, reward, coef):
                                     cur_stream()), "mobody_par_penalty")
 
 
-def adam_polyak_dev(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t_dev, lr, tau=-1.0, grad_scale=1.0):
+def adam_polyak_dev(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t_dev, lr, tau=-1.0, grad_scale=1.0,
+                    target_T=None):
     check(load().mobody_adam_polyak_dev(in_dim, out_dim, members, ptr(blob), ptr(blob_T), ptr(grad), ptr(m), ptr(v),
-                                        ptr(target), ptr(t_dev), float(lr), float(tau), float(grad_scale),
+                                        ptr(target), ptr(target_T), ptr(t_dev), float(lr), float(tau), float(grad_scale),
                                         cur_stream()), "mobody_adam_polyak_dev")
 
 
@@ -378,14 +394,16 @@ def dyn_validate(blob, S, A, obs, act, next_obs, rew, use_trg, ws=None):
 
 
 def rollout(dyn_blob, actor_blob, S, A, task_id, max_action, init_obs, H, elites, seed, call0, penalty_coef, use_penalty,
-            use_trg, env_filter, filter_bad_rollout, buf, cap, ptr_size, ws=None):
+            use_trg, env_filter, filter_bad_rollout, buf, cap, ptr_size, ws=None, dyn_planes=None, actor_blob_T=None,
+            precision=0):
     """H-step on-device rollout of `init_obs` appended to the ring `buf` (mobody_rollout).  Returns the workspace."""
     B = init_obs.shape[0]
     need = load().mobody_rollout_workspace(S, A, B)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1), dtype=torch.float32, device=init_obs.device)
     el = (C.c_int32 * len(elites))(*[int(e) for e in elites])
-    check(load().mobody_rollout(ptr(dyn_blob), ptr(actor_blob), S, A, task_id, float(max_action), ptr(_f32(init_obs)), B, int(H),
+    check(load().mobody_rollout(ptr(dyn_blob), ptr(dyn_planes), ptr(actor_blob), ptr(actor_blob_T), prec_id(precision), S, A,
+                                task_id, float(max_action), ptr(_f32(init_obs)), B, int(H),
                                 el, len(elites), seed, call0, float(penalty_coef), int(bool(use_penalty)), int(bool(use_trg)),
                                 float(env_filter), int(bool(filter_bad_rollout)), *[ptr(t) for t in buf], cap, ptr(ptr_size),
                                 ptr(ws), cur_stream()), "mobody_rollout")

@@ -27,16 +27,16 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mobody_abi_version() == 1
+    assert lib.mobody_abi_version() == 2
 
 
 def test_struct_sizes_match_header(lib):
     from mobody_amd import _lib
     assert C.sizeof(_lib.MobodyLayer) == 32
     assert C.sizeof(_lib.MobodyDynLayout) == 16 + 13 * 32 + 8
-    assert C.sizeof(_lib.MobodyMlpLayout) == 6 * 4 + 13 * 8
+    assert C.sizeof(_lib.MobodyMlpLayout) == 6 * 4 + 15 * 8
     assert C.sizeof(_lib.MobodyTrainDims) == 8 + 4 * 8
-    assert C.sizeof(_lib.MobodyHyper) == 7 * 4
+    assert C.sizeof(_lib.MobodyHyper) == 8 * 4
 
 
 @pytest.mark.parametrize("S,A", [(17, 6), (111, 8), (45, 24), (11, 3)])
@@ -78,9 +78,9 @@ def test_argument_validation_reports_errors(lib):
     d = _lib.MobodyTrainDims(17, 6, 640, 512, 640, 512)
     assert lib.mobody_train_workspace(C.byref(d)) > 640 * 256 * 8
     # empty batches are accepted without touching any pointer
-    assert lib.mobody_dyn_step(None, 17, 6, 4, None, None, 0, None, None, None, None, 0, 0, 0, 0.0, 1, 1, None, None,
+    assert lib.mobody_dyn_step(None, None, 0, 17, 6, 4, None, None, 0, None, None, None, None, 0, 0, 0, 0.0, 1, 1, None, None,
                                None, None, None, None, None, None) == 0
-    assert lib.mobody_dyn_step(None, 17, 6, 99, None, None, 5, None, None, None, None, 0, 0, 0, 0.0, 1, 1, None, None,
+    assert lib.mobody_dyn_step(None, None, 0, 17, 6, 99, None, None, 5, None, None, None, None, 0, 0, 0, 0.0, 1, 1, None, None,
                                None, None, None, None, None, None) == -1
 
 
