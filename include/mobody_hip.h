@@ -227,7 +227,8 @@ typedef struct MobodyTrainDims {
 typedef struct MobodyHyper {
   float gamma, tau, max_action, weight, bc_coef;
   int32_t q_weighted, scale_q;
-  int32_t precision;   /* MFMA mode of the 256 x 256 forward layers: 0 exact fp32 (default, parity), 1 bf16, 2 bf16x2, 3 bf16x3 */
+  int32_t precision;   /* MFMA mode of the 256 x 256 GEMMs of the forward AND backward passes (weight gradients stay fp32):
+                          0 exact fp32 (default, parity), 1 bf16, 2 bf16x2, 3 bf16x3 */
 } MobodyHyper;
 
 /* floats of scratch the training calls need.  The SAME workspace has to be handed to mobody_actor_forward and the

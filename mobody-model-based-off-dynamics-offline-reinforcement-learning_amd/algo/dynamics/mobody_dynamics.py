@@ -59,7 +59,7 @@ class MOBODYEnsembleDynamics(object):
         self.cycle_loss_coef = config["cycle_loss_coef"]
         self.encode_trg_diff = getattr(model, "encode_trg_diff", 0)
         self.rng, self.seed = rng, int(seed)
-        self.precision = ops.prec_id(str(config.get("mfma", "f32")))     # MFMA mode of step(): 0 exact fp32 | bf16 / bf16x2 / bf16x3
+        self.precision = ops.prec_id(str(config.get("mfma", ops.default_mfma())))     # MFMA mode of step(): 0 exact fp32 | bf16 / bf16x2 / bf16x3
         self._calls = 0
         self.noise_fn = None          # optional hook: noise_fn((7, B, S)) -> unit normals (tests)
         self.train_noise_fn = None    # optional hook: b -> (noise6[6,7,b,16], noise7[7,b,S]) device tensors (tests)

@@ -177,7 +177,7 @@ class MOBODYModule(object):
         return self._planes
 
     def _fwd(self, state, action, use_trg):
-        prec = ops.prec_id(self.config.get("mfma", "f32"))
+        prec = ops.prec_id(self.config.get("mfma", ops.default_mfma()))
         mean = ops.dyn_forward(self.packed(), self.obs_dim, self.action_dim, state, action, use_trg,
                                planes=self.planes() if prec else None, precision=prec)
         return mean, None, None        # (mean, zs_mu, zs_logvar): the latent stats are unused by the hot path

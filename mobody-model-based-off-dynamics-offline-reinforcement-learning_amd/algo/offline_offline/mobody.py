@@ -187,7 +187,7 @@ class MOBODY(object):
         S, A = int(config["state_dim"]), int(config["action_dim"])
         self.S, self.A = S, A
         # MFMA mode of the 256 x 256 forward layers: 'f32' exact (default, the parity mode) | 'bf16x3' | 'bf16x2' | 'bf16'
-        self.mfma = str(config.get("mfma", "f32"))
+        self.mfma = str(config.get("mfma", ops.default_mfma()))
         self.precision = ops.prec_id(self.mfma)
         self.rng = config.get("rng", "numpy")               # 'numpy' = reference index/elite streams; 'device' = Philox
         self.seed = int(config.get("seed", 0))

@@ -17,6 +17,7 @@
 // ~2 KB of activations per row); k_grad_reduce is HBM/L2 streaming.
 #include "common.h"
 #include "layers.h"
+#include "tile_bf.h"
 #include "train.h"
 
 namespace mobody {
@@ -30,7 +31,9 @@ namespace mobody {
 // Lanes < 32 end up with the 64-row sums of columns 64w + 32nt + (lane&31), nt = 0,1.
 // MASK: 0 = ReLU mask from the saved activations (h > 0), 1 = ReLU mask from the forward's sign words,
 //       2 = Swish: multiply by the saved derivative d = dy/dz (h points at save_d of the forward, mobody_module.py:9-15).
-template <int MT, int MASK>
+// NPL > 0: the masked gradient goes to NPL bf16 planes in LDS (the next GEMM runs on the split-precision core) instead of
+// the fp32 image; the global copy (the weight-gradient operand) and the column sums stay fp32.
+template <int MT, int MASK, int NPL = 0>
 __device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], float* Xs, const float* __restrict__ h,
                                                        const uint32_t* __restrict__ bits, float* gdst, int rows_here,
                                                        float (&cs)[2]) {
@@ -78,7 +81,15 @@ __device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], flo
             else on = hv[mt][nt][r] > 0.f;
             dz = (on && valid) ? acc[mt][nt][r] : 0.f;
           }
-          Xs[row * LDX + col] = dz;
+          if constexpr (NPL > 0) {
+            __bf16 t[NPL];
+            bf_split<NPL>(dz, t);
+            __bf16* Ps = reinterpret_cast<__bf16*>(Xs);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) Ps[((size_t)p * 32 * MT + row) * LDP + col] = t[p];
+          } else {
+            Xs[row * LDX + col] = dz;
+          }
           if (gdst != nullptr && valid) gdst[row * HID + col] = dz;
           cs[nt] += dz;
         }
@@ -167,7 +178,8 @@ __device__ __forceinline__ void bwd_seed(const Mlp3BwdArgs& a, float* Xs, float*
 // NT (DX only): 16-column tiles of the input-gradient layer handled by the K-split narrow layer (Np1t == 16*NT),
 // or 0 = any Np1t through the row-split path.
 // MASK: see wide_mask_store_colsum (1: sign words m1, m2; 0: saved activations h1, h2; 2: Swish derivatives in h1, h2).
-template <bool DX, int MT, int NT, int MASK>
+// NPL: 0 = exact fp32 MFMA; 1..3 = the 256 x 256 GEMM (dz2 W2^T) on the split-precision bf16 core, streaming W2^T's planes.
+template <bool DX, int MT, int NT, int MASK, int NPL = 0>
 __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   constexpr bool BITS = MASK == 1;
   __shared__ float red[8];
@@ -208,15 +220,20 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdA
   wide_zero<MT>(acc);
   wide_gemm<MT>(Xs, w3t, a.Np3, acc, ring);
   TR(2);
-  wide_prefetch(w2t, HID, ring);                  // next layer's first fragments overlap the mask epilogue
+  constexpr int NPLX = NPL > 0 ? NPL : 1;
+  BfRing<NPLX> bring;
+  const bf16x8* w2tp = NPL > 0 ? reinterpret_cast<const bf16x8*>(a.w2t_planes + m * a.planes_ms) : nullptr;
+  if constexpr (NPL > 0) bf_prefetch<NPLX>(w2tp, bring);
+  else wide_prefetch(w2t, HID, ring);             // next layer's first fragments overlap the mask epilogue
   lds_barrier();
-  wide_mask_store_colsum<MT, MASK>(acc, Xs, h2, m2, dz2, rows_here, cs);
+  wide_mask_store_colsum<MT, MASK, NPL>(acc, Xs, h2, m2, dz2, rows_here, cs);
   if (lane < 32) { dbp[HID + 64 * w + lane] = cs[0]; dbp[HID + 64 * w + 32 + lane] = cs[1]; }
   lds_barrier();
   TR(3);
   // dh1 = dz2 * W2^T ; dz1 = dh1 * [h1 > 0]
   wide_zero<MT>(acc);
-  wide_gemm<MT>(Xs, w2t, HID, acc, ring);
+  if constexpr (NPL > 0) bf_gemm<MT, NPLX>(reinterpret_cast<const __bf16*>(Xs), 32 * MT, w2tp, acc, bring);
+  else wide_gemm<MT>(Xs, w2t, HID, acc, ring);
   TR(4);
   NarrowRegs<(NT > 0 ? NT : 1)> br;
   if constexpr (DX && NT > 0) narrow_prefetch<NT>(w1t, 16 * NT, br);
@@ -237,20 +254,30 @@ __global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdA
   TR(6);
 }
 
-template <bool DX, int MT, int NT, int BITS>
+template <bool DX, int MT, int NT, int BITS, int NPL = 0>
 static int launch_bwd_t(const Mlp3BwdArgs& a, int members, hipStream_t st) {
-  constexpr size_t lds = (size_t)32 * MT * LDX * sizeof(float);
+  constexpr size_t f32b = (size_t)32 * MT * LDX * sizeof(float), plb = (size_t)NPL * 32 * MT * LDP * sizeof(__bf16);
+  constexpr size_t lds = f32b > plb ? f32b : plb;
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_mlp3_bwd<DX, MT, NT, BITS>, lds);
+    int rc = allow_big_lds(k_mlp3_bwd<DX, MT, NT, BITS, NPL>, lds);
     if (rc) return rc;
     once = true;
   }
   dim3 grid((unsigned)cdiv(a.rows, 32 * MT), (unsigned)members);
   ProfScope prof(PROF_MLP_BWD, st);
-  hipLaunchKernelGGL((k_mlp3_bwd<DX, MT, NT, BITS>), grid, dim3(NTHREADS), lds, st, a);
+  hipLaunchKernelGGL((k_mlp3_bwd<DX, MT, NT, BITS, NPL>), grid, dim3(NTHREADS), lds, st, a);
   MB_LAUNCH_OK("k_mlp3_bwd");
   return 0;
+}
+
+// split-precision backward: sign-word masks, 32-row tiles (the train step's three backward launches)
+template <int NPL>
+static int launch_bwd_bf(const Mlp3BwdArgs& a, int members, bool with_dx, hipStream_t st) {
+  const int nt = a.Np1t == 16 ? 1 : a.Np1t == 32 ? 2 : 0;
+  if (!with_dx) return launch_bwd_t<false, 1, 0, 1, NPL>(a, members, st);
+  return nt == 1 ? launch_bwd_t<true, 1, 1, 1, NPL>(a, members, st) : nt == 2 ? launch_bwd_t<true, 1, 2, 1, NPL>(a, members, st)
+                                                                             : launch_bwd_t<true, 1, 0, 1, NPL>(a, members, st);
 }
 
 // tile_rows (32 or 64) must be the value the caller sized `dbp` / the bias reduction with
@@ -281,6 +308,9 @@ int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, int tile_ro
     if (tile_rows != 32) return fail(MOBODY_E_ARG, "launch_mlp3_bwd: the Swish backward uses 32-row tiles");
     return launch_bwd_swish(a, members, with_dx, st);
   }
+  if (a.prec != 0 && a.w2t_planes != nullptr && a.m1 != nullptr && a.m2 != nullptr && tile_rows == 32)
+    return a.prec == 1 ? launch_bwd_bf<1>(a, members, with_dx, st) : a.prec == 2 ? launch_bwd_bf<2>(a, members, with_dx, st)
+                                                                                 : launch_bwd_bf<3>(a, members, with_dx, st);
   return a.m1 != nullptr && a.m2 != nullptr ? launch_bwd_masks<1>(a, members, with_dx, tile_rows, st)
                                             : launch_bwd_masks<0>(a, members, with_dx, tile_rows, st);
 }

@@ -56,6 +56,9 @@ struct Mlp3BwdArgs {
   const uint32_t* m1;      // [members][ceil(rows/32)][256] sign bits of h1 / h2 written by the forward; when both are
   const uint32_t* m2;      // given they replace h1 / h2 (which may then be null)
   const float* wt;         // transposed blob (member 0)
+  const unsigned short* w2t_planes;   // bf16 planes of W2^T (member 0; wt + L.w2tp) and the precision (0 = exact fp32 MFMA)
+  long long planes_ms;
+  int prec;
   long long t_mstride, w3t, w2t, w1t;
   int Np3, Np1t;
   long long rows;

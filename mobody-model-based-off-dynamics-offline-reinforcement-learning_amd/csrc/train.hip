@@ -239,8 +239,9 @@ static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h
 
 static Mlp3BwdArgs bwd_args(const MobodyMlpLayout& L, const float* blob_T, const float* dz3, const float* h1,
                             const float* h2, long long rows, float* dz2, float* dz1, float* dbp,
-                            const uint32_t* m1 = nullptr, const uint32_t* m2 = nullptr) {
+                            const uint32_t* m1 = nullptr, const uint32_t* m2 = nullptr, int prec = 0) {
   Mlp3BwdArgs b{};
+  b.prec = prec; b.w2t_planes = reinterpret_cast<const unsigned short*>(blob_T + L.w2tp); b.planes_ms = 2 * L.t_member_floats;
   b.dz3 = dz3; b.h1 = h1; b.h2 = h2; b.m1 = m1; b.m2 = m2; b.wt = blob_T; b.t_mstride = L.t_member_floats;
   b.w3t = L.w3t; b.w2t = L.w2t; b.w1t = L.w1t; b.Np3 = L.Np3; b.Np1t = L.Np1t; b.rows = rows;
   b.dz2 = dz2; b.dz1 = dz1; b.dbp = dbp;
@@ -300,7 +301,7 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
   if (rc) return rc;
   const float invNg = 1.f / (float)d->N_global;
   // TD error -> dz3 in the backward's prologue (mobody.py:190-207), then dz2, dz1 and the bias partials
-  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp, w.mq1, w.mq2);
+  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp, w.mq1, w.mq2, prec);
   bq.seed.mode = 1; bq.seed.q = w.q; bq.seed.qt = w.qt; bq.seed.qnext = q_next; bq.seed.r = reward; bq.seed.nd = not_done;
   bq.seed.gamma = h->gamma; bq.seed.inv_ng = invNg; bq.seed.dz3_out = w.dz3q; bq.seed.lossp = w.lossp;
   rc = launch_mlp3_bwd(bq, 2, false, w.tile_rows, st);
@@ -381,6 +382,8 @@ static int actor_backward_impl(const MobodyTrainDims* d, const MobodyHyper* h, c
   if (rc) return rc;
   MB_REQUIRE(h && actor_blob && actor_blob_T && q_blob && q_blob_T && state && action && stats && (grad_actor || adam.on) &&
                  loss_out && workspace, "mobody_actor_backward: null pointer");
+  rc = check_prec(h, "mobody_actor_backward", true);
+  if (rc) return rc;
   TrainWs w;
   rc = carve(*d, workspace, w);
   if (rc) return rc;
@@ -392,13 +395,13 @@ static int actor_backward_impl(const MobodyTrainDims* d, const MobodyHyper* h, c
   ra.A = d->A; ra.h = *h;
   // dq -> d(action) through the frozen twin-Q (parameters get no gradient, mobody.py:555-556); the prologue forms
   // -p_w/N d min(q1,q2) and the BC weights
-  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, nullptr, nullptr, nullptr, N, nullptr, nullptr, w.dbp, w.mq1, w.mq2);
+  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, nullptr, nullptr, nullptr, N, nullptr, nullptr, w.dbp, w.mq1, w.mq2, h->precision);
   bq.seed.mode = 2; bq.seed.ar = ra;
   bq.dx = w.dxa; bq.dx_c0 = d->S; bq.dx_n = d->A;
   rc = launch_mlp3_bwd(bq, 2, true, w.tile_rows, st);
   if (rc) return rc;
   // actor: d(pre-tanh) from both members' dx and the BC term in the prologue, then the actor's own backward
-  Mlp3BwdArgs ba = bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp, w.ma1, w.ma2);
+  Mlp3BwdArgs ba = bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp, w.ma1, w.ma2, h->precision);
   ba.seed.mode = 3; ba.seed.ar = ra; ba.seed.dz3_out = w.dz3a; ba.seed.lossp = w.lossp;
   rc = launch_mlp3_bwd(ba, 1, false, w.tile_rows, st);
   if (rc) return rc;

@@ -35,6 +35,13 @@ def prec_id(mfma):
     return mfma if isinstance(mfma, int) else _lib.PRECISIONS[mfma]
 
 
+def default_mfma():
+    """MFMA mode when a config does not name one: exact fp32, unless MOBODY_MFMA says otherwise (how the whole parity
+    suite is re-run in a split-precision mode: `MOBODY_MFMA=bf16x3 pytest -m gpu`)."""
+    import os
+    return os.environ.get("MOBODY_MFMA", "f32")
+
+
 def dyn_planes(blob, S, A, out=None):
     """bf16 planes of zs2 / transition2 / reward_model2 for the split-precision modes."""
     pl = out if out is not None else torch.empty(load().mobody_dyn_planes_floats(), dtype=torch.float32, device=blob.device)
@@ -118,7 +125,7 @@ def train_dims(S, A, N, Nt, N_global=None, Nt_global=None):
 def hyper(cfg):
     return _lib.MobodyHyper(float(cfg["gamma"]), float(cfg["tau"]), float(cfg["max_action"]), float(cfg["weight"]),
                             float(cfg["bc_coef"]), int(bool(cfg["q_weighted"])), int(bool(cfg["scale_Q"])),
-                            prec_id(cfg.get("mfma", "f32")))
+                            prec_id(cfg.get("mfma", default_mfma())))
 
 
 def train_workspace(dims, device):
