@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 
 PEAK_F32_TFLOPS = 157.3          # MI355X dense fp32 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak
 FAMILIES = ["k_mlp3_fwd", "k_mlp3_bwd", "k_wgrad", "k_dyn_fwd"]
 CONFIGS = {   # BASELINE.json configs[i] -> shapes (per GPU)
     "c1": dict(S=17, A=6, bs=256, H=1, task="walker2d-medium-v2", penalty_type="none",
@@ -66,6 +67,25 @@ def train_flops(S, A, N, Nt):
     return {"k_mlp3_fwd": 2.0 * fwd, "k_mlp3_bwd": 2.0 * bwd, "k_wgrad": 2.0 * wg}
 
 
+def wide_flops(S, A, N, Nt):
+    """The part of each family's FLOPs that sits in 256 x 256 GEMMs -- what the split-precision modes move to the bf16 core
+    (forward: one per network pass; backward: dz2 W2^T, one per network pass; weight gradients: none, they stay fp32)."""
+    return {"k_mlp3_fwd": 2.0 * 65536 * (8 * N + 2 * Nt), "k_mlp3_bwd": 2.0 * 65536 * 5 * N, "k_wgrad": 0.0}
+
+
+NPROD = {"f32": 0, "bf16": 1, "bf16x2": 3, "bf16x3": 6}
+
+
+def effective_peak(total_flops, wide, mfma):
+    """MFMA roofline of a kernel whose instruction mix is part exact fp32 MFMA, part bf16 MFMA with NPROD products per
+    fp32 product: the time both pipes need at their dense peaks (157.3 TF fp32-input, 2.5 PF bf16; MI355X_MICROARCH.md),
+    expressed as fp32-equivalent TFLOP/s of the kernel's ALGORITHMIC flops."""
+    if NPROD[mfma] == 0:
+        return PEAK_F32_TFLOPS
+    t_min = (total_flops - wide) / (PEAK_F32_TFLOPS * 1e12) + wide * NPROD[mfma] / (PEAK_BF16_TFLOPS * 1e12)
+    return total_flops / t_min / 1e12
+
+
 # ------------------------------------------------------------------------------------------------ launcher
 def spawn_ranks(args):
     """Parent of `--gpus N` (no launcher in the environment): start N children, one per GPU, BEFORE anything here
@@ -88,7 +108,7 @@ def spawn_ranks(args):
 
 
 # ------------------------------------------------------------------------------------------------ GPU side
-def build(dev, c, graph, mfma="f32"):
+def build(dev, c, graph, mfma="f32", buffers=None):
     import numpy as np
     import torch
     from mobody_amd import engine, synthetic
@@ -104,8 +124,11 @@ def build(dev, c, graph, mfma="f32"):
                                 src_rollout_length=c["H"], trg_rollout_length=c["H"], mfma=mfma)
     torch.manual_seed(0); np.random.seed(0)
     pol = call_algo("mobody", cfg, 3, dev)
-    src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=1000000, rng="device", seed=100), 1000000, task, 0)
-    tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=5000, rng="device", seed=200), 5000, task, 1000)
+    if buffers is not None:
+        src, tar = buffers
+    else:
+        src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=1000000, rng="device", seed=100), 1000000, task, 0)
+        tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=5000, rng="device", seed=200), 5000, task, 1000)
     model = synthetic.alive_dynamics(MOBODYModule(S, A, 256, 7, 5, device=dev, config=cfg), task)
     pol.dynamics = MOBODYEnsembleDynamics(cfg, model, None, None, get_termination_fn(task), penalty_coef=0.1, rng="device", seed=300)
     return pol, src, tar, cfg
@@ -278,8 +301,10 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch_size", type=int, default=None, help="override the config's per-GPU batch size")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--mfma", default="f32", choices=["f32", "bf16x3", "bf16x2", "bf16"],
-                    help="MFMA mode of the 256 x 256 forward layers: exact fp32 (parity mode) or a split-precision bf16 mode")
+    ap.add_argument("--mfma", default="bf16x3", choices=["f32", "bf16x3", "bf16x2", "bf16"],
+                    help="MFMA mode of the 256 x 256 forward / backward GEMMs: bf16x3 (default: three-term split, six products, holds the "
+                         "fp32 parity tolerances), exact fp32 (the parity-test mode), bf16x2 (~6e-6) or plain bf16 (~3e-3)")
+    ap.add_argument("--no_mode_sweep", action="store_true", help="skip the short runs of the other MFMA modes")
     ap.add_argument("--graph", type=int, default=1, help="HIP-graph replay of the steady-state step: 0 never, 1 always, 2 auto (minibatches under 4096 rows); with N > 1 ranks the segments between the three all-reduces are replayed")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -341,6 +366,25 @@ def main():
         torch.distributed.all_gather(hs, h)
         replicas_identical = all(torch.equal(hs[0], x) for x in hs)
 
+    # the other MFMA modes, 100 steps each on the same buffers (extra information; the headline is args.mfma)
+    sweep = {}
+    if not args.no_mode_sweep:
+        for mode in ("f32", "bf16x3", "bf16x2", "bf16"):
+            if mode == args.mfma:
+                continue
+            p2 = build(dev, c, args.graph, mode, buffers=(src, tar))[0]
+            for _ in range(12):
+                p2.train(src, tar, bs, None, None)
+            barrier()
+            ts = time.perf_counter()
+            for _ in range(100):
+                p2.train(src, tar, bs, None, None)
+            barrier()
+            tq = torch.tensor([time.perf_counter() - ts], dtype=torch.float64, device=dev)
+            if world > 1:
+                torch.distributed.all_reduce(tq, op=torch.distributed.ReduceOp.MAX)
+            sweep[mode] = dict(ms_per_step_refresh_excluded=float(tq[0]) / 100 * 1e3, grad_steps_per_sec=100 / float(tq[0]))
+            del p2
     # the instrumented passes call train() (collectives when world > 1): every rank runs them, rank 0 reports
     fam = prof_pass(pol, src, tar, bs, 20)
     roll_rate, roll_ms, dynfwd_ms = rollout_rate(pol, src, c["H"])
@@ -358,9 +402,13 @@ def main():
         d = kern[dom]
         per_launch_flops = fl[dom] / d["launches_per_step"]
         avg_ms = d["ms_per_step"] / d["launches_per_step"]
-        roofline = dict(kernel=dom, bound="mfma", achieved=per_launch_flops / (avg_ms * 1e-3) / 1e12, peak=PEAK_F32_TFLOPS,
+        peak = effective_peak(fl[dom], wide_flops(S, A, N, Nt)[dom], args.mfma)
+        roofline = dict(kernel=dom, bound="mfma", achieved=per_launch_flops / (avg_ms * 1e-3) / 1e12, peak=peak,
                         unit="TFLOP/s", traffic=None, avg_launch_ms=avg_ms, launches_per_step=d["launches_per_step"],
-                        flops_per_launch=per_launch_flops)
+                        flops_per_launch=per_launch_flops,
+                        peak_note="fp32-equivalent TFLOP/s of the kernel's algorithmic flops if its fp32-MFMA part ran at 157.3 TF and "
+                                  f"its 256x256 GEMMs ({NPROD[args.mfma]} bf16 MFMAs per fp32 product) at 2.5 PF" if args.mfma != "f32"
+                                  else "dense fp32-input MFMA peak")
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         # HBM bytes of one launch of the dominant kernel: PMC counters need their own rocprofv3 passes (FETCH_SIZE and
         # WRITE_SIZE cannot share one, and not with a timing run), so the figure comes from the committed summary of
@@ -395,6 +443,7 @@ def main():
             "rollout_transitions_per_sec": roll_rate, "rollout_ms_per_call": roll_ms,
             "rollout_rows_in_timed_region": rolled,
             "roofline": roofline, "kernels": kern, "final_losses": losses, "replicas_identical": replicas_identical,
+            "other_mfma_modes": sweep,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, cfg)

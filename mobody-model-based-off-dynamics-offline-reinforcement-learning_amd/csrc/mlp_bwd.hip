@@ -180,7 +180,10 @@ __device__ __forceinline__ void bwd_seed(const Mlp3BwdArgs& a, float* Xs, float*
 // MASK: see wide_mask_store_colsum (1: sign words m1, m2; 0: saved activations h1, h2; 2: Swish derivatives in h1, h2).
 // NPL: 0 = exact fp32 MFMA; 1..3 = the 256 x 256 GEMM (dz2 W2^T) on the split-precision bf16 core, streaming W2^T's planes.
 template <bool DX, int MT, int NT, int MASK, int NPL = 0>
-__global__ __launch_bounds__(NTHREADS, MT == 1 ? 3 : 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
+// (three workgroups per CU only for the sign-word variants: the variants that hold 32 mask / derivative values per lane next to
+//  the accumulators spilled ~26 VGPRs at the 168-register budget; they serve the small generic launches -- V function, DARA
+//  classifier, dynamics pre-training -- where a third resident workgroup buys nothing)
+__global__ __launch_bounds__(NTHREADS, (MT == 1 && MASK == 1) ? 3 : 2) void k_mlp3_bwd(Mlp3BwdArgs a) {
   constexpr bool BITS = MASK == 1;
   __shared__ float red[8];
   extern __shared__ __attribute__((aligned(16))) float Xs[];
