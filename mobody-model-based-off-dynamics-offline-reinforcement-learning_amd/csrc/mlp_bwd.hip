@@ -15,6 +15,8 @@
 //
 // Roofline: k_mlp3_bwd and k_wgrad are MFMA-f32 bound (2*256*256 FLOP per row and layer against
 // ~2 KB of activations per row); k_grad_reduce is HBM/L2 streaming.
+#include <stdlib.h>
+
 #include "common.h"
 #include "layers.h"
 #include "tile_bf.h"
@@ -429,6 +431,119 @@ __device__ __forceinline__ void wgrad_tile(const WgradJob& jb, const WgradArgs& 
   }
 }
 
+// Split-precision form of the 256 x 256 job (dW2 = h1^T dz2, 86 % of the weight-gradient FLOPs): the contraction runs over
+// batch ROWS, so a lane's A / B fragment of v_mfma_f32_32x32x16_bf16 is eight consecutive rows of one column -- eight
+// coalesced scalar loads (a wave instruction = 2 rows x 128 bytes), split into NPL bf16 terms in registers, then the
+// (i + j < NPL) products.  Same work split, LDS reduction and slab output as wgrad_tile<2>.
+template <int NPL>
+__device__ __forceinline__ void wgrad_tile_bf(const WgradJob& jb, const WgradArgs& a, int tile, int slice, int m, float* red) {
+  constexpr int MT = 2, NT = 2, TK = 64, TN = 64;
+  const int lane = lane_id(), w = wave_id();
+  const int i = lane & 31, h = lane >> 5;
+  const int tk = tile / jb.tiles_n, tn = tile - tk * jb.tiles_n;
+  const int k0 = tk * TK, n0 = tn * TN;
+  const float* A = jb.A + m * jb.a_mstride;
+  const float* B = jb.B + m * jb.b_mstride;
+  const long long r_begin = ((long long)slice * 4 + w) * a.rows_per_wave;
+  const long long r_end = min(a.rows, r_begin + a.rows_per_wave);
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int x = 0; x < MT; ++x)
+#pragma unroll
+    for (int y = 0; y < NT; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  const float* pa[MT]; const float* pb[NT];                      // job 0: every column is real (ka = nb = 256)
+#pragma unroll
+  for (int x = 0; x < MT; ++x) pa[x] = A + k0 + 32 * x + i;
+#pragma unroll
+  for (int y = 0; y < NT; ++y) pb[y] = B + n0 + 32 * y + i;
+  auto load = [&](long long rb, float (&av)[MT][8], float (&bv)[NT][8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      long long row = rb + 8 * h + j;
+      const float rv = row < r_end ? 1.f : 0.f;
+      row = row < r_end ? row : r_begin;
+#pragma unroll
+      for (int x = 0; x < MT; ++x) av[x][j] = pa[x][row * jb.lda] * rv;
+#pragma unroll
+      for (int y = 0; y < NT; ++y) bv[y][j] = pb[y][row * jb.ldb] * rv;
+    }
+  };
+  auto pack = [&](const float (&v)[8], bf16x8 (&f)[NPL]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 t[NPL];
+      bf_split<NPL>(v[j], t);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) f[p][j] = t[p];
+    }
+  };
+  auto mma = [&](const float (&av)[MT][8], const float (&bv)[NT][8]) {
+    bf16x8 af[MT][NPL], bfr[NT][NPL];
+#pragma unroll
+    for (int x = 0; x < MT; ++x) pack(av[x], af[x]);
+#pragma unroll
+    for (int y = 0; y < NT; ++y) pack(bv[y], bfr[y]);
+#pragma unroll
+    for (int x = 0; x < MT; ++x)
+#pragma unroll
+      for (int y = 0; y < NT; ++y)
+#pragma unroll
+        for (int d = NPL - 1; d >= 0; --d)
+#pragma unroll
+          for (int q = 0; q <= d; ++q)
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[x][q], bfr[y][d - q], acc[x][y], 0, 0, 0);
+  };
+  if (r_begin < r_end) {
+    float a0[MT][8], b0[NT][8], a1[MT][8], b1[NT][8];
+    load(r_begin, a0, b0);
+    for (long long rb = r_begin; rb < r_end; rb += 32) {
+      if (rb + 16 < r_end) load(rb + 16, a1, b1);
+      mma(a0, b0);
+      if (rb + 16 < r_end) {
+        if (rb + 32 < r_end) load(rb + 32, a0, b0);
+        mma(a1, b1);
+      }
+    }
+  }
+  float* mine = red + (w & 1) * (TK * TN);
+  auto sweep = [&](bool add) {
+#pragma unroll
+    for (int x = 0; x < MT; ++x)
+#pragma unroll
+      for (int y = 0; y < NT; ++y)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kk = 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
+          float* p = mine + kk * TN + 32 * y + i;
+          *p = add ? *p + acc[x][y][r] : acc[x][y][r];
+        }
+  };
+  if (w < 2) sweep(false);
+  __syncthreads();
+  if (w >= 2) sweep(true);
+  __syncthreads();
+  float* slab = a.slabs + (long long)slice * a.slab_stride + jb.out_off + m * a.out_mstride;
+  for (int idx = threadIdx.x; idx < TK * TN; idx += NTHREADS) {
+    const int kk = idx / TN, nn = idx - kk * TN;
+    slab[wide_idx(k0 + kk, n0 + nn)] = red[idx] + red[TK * TN + idx];
+  }
+}
+
+template <int NPL>
+__global__ __launch_bounds__(NTHREADS, 2) void k_wgrad_bf(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];     // [2][64][64]
+  const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+  const int sm = xcd + 8 * (j / a.tiles_total);
+  const int t = j % a.tiles_total;
+  if (sm >= a.nsplit * a.members) return;
+  const int slice = sm / a.members, m = sm - slice * a.members;
+  if (t < a.job[0].ntiles) wgrad_tile_bf<NPL>(a.job[0], a, t, slice, m, red);
+  else if (t < a.job[0].ntiles + a.job[1].ntiles) wgrad_tile<1>(a.job[1], a, t - a.job[0].ntiles, slice, m, red);
+  else wgrad_tile<1>(a.job[2], a, t - a.job[0].ntiles - a.job[1].ntiles, slice, m, red);
+}
+
 __global__ __launch_bounds__(NTHREADS, 4) void k_wgrad(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float red[];     // [2][64][64]
   // XCD-aware decode: blocks with equal (id % 8) share an XCD; consecutive ones walk the tiles of one (slice, member)
@@ -459,6 +574,26 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
   const int sm = a.nsplit * a.members;
   const int blocks = 8 * ((sm + 7) / 8) * a.tiles_total;
   ProfScope prof(PROF_WGRAD, st);
+  // Split-precision job 0 -- only in the plain bf16 mode: splitting the operands in registers costs ~6 VALU instructions per
+  // value and term, which at two / three terms eats what the faster MFMAs give (measured per step at c2: 0.078 ms fp32,
+  // 0.078 bf16x2, 0.082 bf16x3, 0.053 bf16); MOBODY_WGRAD_BF=1 forces it for every mode, =0 disables it (tuning aids).
+  static const int bf_force = [] { const char* e = getenv("MOBODY_WGRAD_BF"); return e ? atoi(e) : -1; }();
+  const bool use_bf = bf_force == 1 ? a.prec != 0 : bf_force == 0 ? false : a.prec == 1;
+  if (use_bf && a.job[0].ka == HID && a.job[0].nb == HID && a.job[0].wide) {
+    static bool once_bf = false;
+    if (!once_bf) {
+      int rc = allow_big_lds(k_wgrad_bf<1>, lds);
+      if (!rc) rc = allow_big_lds(k_wgrad_bf<2>, lds);
+      if (!rc) rc = allow_big_lds(k_wgrad_bf<3>, lds);
+      if (rc) return rc;
+      once_bf = true;
+    }
+    if (a.prec == 1) hipLaunchKernelGGL(k_wgrad_bf<1>, dim3(blocks), dim3(NTHREADS), lds, st, a);
+    else if (a.prec == 2) hipLaunchKernelGGL(k_wgrad_bf<2>, dim3(blocks), dim3(NTHREADS), lds, st, a);
+    else hipLaunchKernelGGL(k_wgrad_bf<3>, dim3(blocks), dim3(NTHREADS), lds, st, a);
+    MB_LAUNCH_OK("k_wgrad_bf");
+    return 0;
+  }
   hipLaunchKernelGGL(k_wgrad, dim3(blocks), dim3(NTHREADS), lds, st, a);
   MB_LAUNCH_OK("k_wgrad");
   return 0;
@@ -538,8 +673,9 @@ __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
 int mlp3_weight_grads(const MobodyMlpLayout& L, const float* x, long long x_mstride, const float* h1, const float* h2,
                       const float* dz3, const float* dz2, const float* dz1, long long rows, int nsplit, float* slabs,
                       const float* dbp, int ntiles, float* grad, const LossFinal& loss, const AdamTarget& adam,
-                      hipStream_t st) {
+                      hipStream_t st, int prec) {
   WgradArgs g{};
+  g.prec = prec;
   const long long slab_stride = (L.total_floats + 3) & ~3LL;
   g.rows = rows; g.slabs = slabs; g.slab_stride = slab_stride; g.out_mstride = L.member_floats;
   g.nsplit = nsplit; g.members = L.members;

@@ -83,6 +83,7 @@ struct WgradArgs {
   long long rows, rows_per_wave;
   float* slabs; long long slab_stride, out_mstride;    // partial slab s = slabs + s*slab_stride (gradient-blob layout)
   int nsplit, members, tiles_total;
+  int prec;                                            // 0 exact fp32; 1..3: the 256 x 256 job on the split-precision bf16 core
 };
 int launch_wgrad(WgradArgs a, hipStream_t st);
 
@@ -206,7 +207,7 @@ int launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);
 int mlp3_weight_grads(const MobodyMlpLayout& L, const float* x, long long x_mstride, const float* h1, const float* h2,
                       const float* dz3, const float* dz2, const float* dz1, long long rows, int nsplit, float* slabs,
                       const float* dbp, int ntiles, float* grad, const LossFinal& loss, const AdamTarget& adam,
-                      hipStream_t st);
+                      hipStream_t st, int prec = 0);
 
 // split-K factor (workgroups along the row dimension) used for a batch of `rows`: 24 output tiles x nsplit x members
 // workgroups should reach ~3 per CU (768), so a one-member net splits twice as fine as a twin net

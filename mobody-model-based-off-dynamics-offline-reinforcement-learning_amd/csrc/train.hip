@@ -232,9 +232,9 @@ static int check_prec(const MobodyHyper* h, const char* who, bool have_planes) {
 // weight gradients of one packed MLP: one merged split-K launch + the deterministic reduction
 static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h1, const float* h2, const float* dz3,
                         const float* dz2, const float* dz1, long long rows, const TrainWs& w, float* grad,
-                        const LossFinal& loss, const AdamTarget& adam, hipStream_t st) {
+                        const LossFinal& loss, const AdamTarget& adam, hipStream_t st, int prec = 0) {
   return mlp3_weight_grads(L, x, 0, h1, h2, dz3, dz2, dz1, rows, L.members == 1 ? w.nsplit_a : w.nsplit_q, w.slabs, w.dbp,
-                           w.ntiles, grad, loss, adam, st);
+                           w.ntiles, grad, loss, adam, st, prec);
 }
 
 static Mlp3BwdArgs bwd_args(const MobodyMlpLayout& L, const float* blob_T, const float* dz3, const float* h1,
@@ -308,7 +308,7 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
   if (rc) return rc;
   LossFinal lf{};                                  // q_loss = mse(q1,y)+mse(q2,y), local share of the global mean
   lf.kind = 1; lf.nparts = 2 * w.ntiles; lf.scale = invNg; lf.parts = w.lossp; lf.out = loss_out;
-  return weight_grads(w.Lq, w.xq, w.h1q, w.h2q, w.dz3q, w.dz2, w.dz1, N, w, grad_q, lf, adam, st);
+  return weight_grads(w.Lq, w.xq, w.h1q, w.h2q, w.dz3q, w.dz2, w.dz1, N, w, grad_q, lf, adam, st, prec);
 }
 
 extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
@@ -408,7 +408,7 @@ static int actor_backward_impl(const MobodyTrainDims* d, const MobodyHyper* h, c
   LossFinal lf{};                                  // loss_out[0] = p_w*mean(-q) + bc_coef*L_BC, [1] = L_BC (local shares)
   lf.kind = 2; lf.nparts = w.ntiles; lf.scale_q = h->scale_q; lf.weight = h->weight; lf.bc_coef = h->bc_coef;
   lf.ng = (float)ra.Ng; lf.ntg_a = (float)ra.Ntg * (float)ra.A; lf.parts = w.lossp; lf.stats = stats; lf.out = loss_out;
-  return weight_grads(w.La, w.xa, w.h1a, w.h2a, w.dz3a, w.dz2, w.dz1, N, w, grad_actor, lf, adam, st);
+  return weight_grads(w.La, w.xa, w.h1a, w.h2a, w.dz3a, w.dz2, w.dz1, N, w, grad_actor, lf, adam, st, h->precision);
 }
 
 extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
