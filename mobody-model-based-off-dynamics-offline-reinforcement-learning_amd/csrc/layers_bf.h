@@ -61,6 +61,7 @@ __device__ __forceinline__ void bf_layer(float* Xs, const __bf16* Ps, int rows_t
   f32x16 acc[MT][2];
   wide_zero<MT>(acc);
   bf_gemm<MT, NPL>(Ps, rows_total, Wb, acc, ring);
+  TR(3);
   between();
   lds_barrier();
   auto body = [&](auto guarded) {

@@ -331,76 +331,29 @@ int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, int tile_ro
 // every wave instruction is two full 128-byte lines, no LDS staging.  Split-K: the 4 waves of a workgroup take
 // 4 consecutive row slices of the same output tile and reduce through LDS; workgroups along the row dimension
 // write separate slabs (deterministic, summed by k_grad_reduce).  Operands of the next 8 rows are prefetched
-// into a second register set while the current 8 rows feed the MFMAs.
+// into a second register set while the current 8 rows feed the MFMAs (see wgrad_tile for what makes that overlap real).
 // Block -> work mapping is XCD aware (blocks b and b+8 share an XCD and its L2): all output tiles of one
 // (row slice, member) run on the same XCD back to back, so the slice's activations are fetched from
 // HBM/Infinity Cache once and re-read 4x from that XCD's L2.
 // ------------------------------------------------------------------------------------------------
-template <int MT>
-__device__ __forceinline__ void wgrad_tile(const WgradJob& jb, const WgradArgs& a, int tile, int slice, int m, float* red) {
-  constexpr int NT = 2, TK = 32 * MT, TN = 32 * NT, U = 4;
+// Buffer descriptor over `nrows` rows of a row-major fp32 matrix (pitch ld floats) starting at the wave-uniform pointer p, and a
+// dword load through it: the per-lane byte offset rides in voffset, the wave-uniform row offset in soffset (a scalar register).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slice_rsrc(const float* p, int nrows, int ld) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)((unsigned)nrows * (unsigned)ld * 4u), 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+
+// Reduce the four row slices of a workgroup through LDS and write one slab tile.  Two tile buffers (32 KB), not four:
+// waves 0,1 store, waves 2,3 add onto them (same lane <-> element map, so no conflicts).  With four buffers (64 KB)
+// only two workgroups fit a CU and a 768-workgroup launch needs two rounds.
+template <int MT, int NT>
+__device__ __forceinline__ void wgrad_store(const WgradJob& jb, const WgradArgs& a, f32x16 (&acc)[MT][NT], int k0, int n0,
+                                            int slice, int m, float* red) {
+  constexpr int TK = 32 * MT, TN = 32 * NT;
   const int lane = lane_id(), w = wave_id();
   const int i = lane & 31, h = lane >> 5;
-  const int tk = tile / jb.tiles_n, tn = tile - tk * jb.tiles_n;
-  const int k0 = tk * TK, n0 = tn * TN;
-  const float* A = jb.A + m * jb.a_mstride;
-  const float* B = jb.B + m * jb.b_mstride;
-  const long long r_begin = ((long long)slice * 4 + w) * a.rows_per_wave;
-  const long long r_end = min(a.rows, r_begin + a.rows_per_wave);
-
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int x = 0; x < MT; ++x)
-#pragma unroll
-    for (int y = 0; y < NT; ++y)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-
-  // column masks folded into clamped pointers + 0/1 multipliers (loads stay unconditional and in bounds)
-  const float* pa[MT]; float fa[MT];
-  const float* pb[NT]; float fb[NT];
-#pragma unroll
-  for (int x = 0; x < MT; ++x) { const int c = k0 + 32 * x + i; fa[x] = c < jb.ka ? 1.f : 0.f; pa[x] = A + (c < jb.ka ? c : 0); }
-#pragma unroll
-  for (int y = 0; y < NT; ++y) { const int c = n0 + 32 * y + i; fb[y] = c < jb.nb ? 1.f : 0.f; pb[y] = B + (c < jb.nb ? c : 0); }
-
-  auto load = [&](long long rb, float (&av)[U][MT], float (&bv)[U][NT]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      long long row = rb + 2 * u + h;                 // lane half h takes the odd row of each pair
-      const float rv = row < r_end ? 1.f : 0.f;
-      row = row < r_end ? row : r_begin;              // r_begin < rows whenever this wave has work
-#pragma unroll
-      for (int x = 0; x < MT; ++x) av[u][x] = pa[x][row * jb.lda] * (fa[x] * rv);
-#pragma unroll
-      for (int y = 0; y < NT; ++y) bv[u][y] = pb[y][row * jb.ldb] * (fb[y] * rv);
-    }
-  };
-  auto mma = [&](float (&av)[U][MT], float (&bv)[U][NT]) {
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int x = 0; x < MT; ++x)
-#pragma unroll
-        for (int y = 0; y < NT; ++y)
-          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][x], bv[u][y], acc[x][y], 0, 0, 0);
-  };
-  if (r_begin < r_end) {
-    float a0[U][MT], b0[U][NT], a1[U][MT], b1[U][NT];
-    load(r_begin, a0, b0);
-    for (long long rb = r_begin; rb < r_end; rb += 4 * U) {
-      if (rb + 2 * U < r_end) load(rb + 2 * U, a1, b1);
-      mma(a0, b0);
-      if (rb + 2 * U < r_end) {
-        if (rb + 4 * U < r_end) load(rb + 4 * U, a0, b0);
-        mma(a1, b1);
-      }
-    }
-  }
-
-  // ---- reduce the four row slices of this workgroup through LDS, write one slab tile ----
-  // Two tile buffers (32 KB), not four: waves 0,1 store, waves 2,3 add onto them (same lane <-> element map, so no
-  // conflicts).  With four buffers (64 KB) only two workgroups fit a CU and a 768-workgroup launch needs two rounds.
   float* mine = red + (w & 1) * (TK * TN);
   auto sweep = [&](bool add) {
 #pragma unroll
@@ -431,21 +384,23 @@ __device__ __forceinline__ void wgrad_tile(const WgradJob& jb, const WgradArgs& 
   }
 }
 
-// Split-precision form of the 256 x 256 job (dW2 = h1^T dz2, 86 % of the weight-gradient FLOPs): the contraction runs over
-// batch ROWS, so a lane's A / B fragment of v_mfma_f32_32x32x16_bf16 is eight consecutive rows of one column -- eight
-// coalesced scalar loads (a wave instruction = 2 rows x 128 bytes), split into NPL bf16 terms in registers, then the
-// (i + j < NPL) products.  Same work split, LDS reduction and slab output as wgrad_tile<2>.
-template <int NPL>
-__device__ __forceinline__ void wgrad_tile_bf(const WgradJob& jb, const WgradArgs& a, int tile, int slice, int m, float* red) {
-  constexpr int MT = 2, NT = 2, TK = 64, TN = 64;
-  const int lane = lane_id(), w = wave_id();
+// The row loop runs on wave-uniform row-block pointers (scalar registers) plus one per-lane 32-bit offset per operand
+// column block, so a load costs no vector arithmetic, and whole row blocks carry no masks: the loaded registers feed the
+// MFMAs directly and the loads of block n+1 stay in flight under the MFMAs of block n.  (Multiplying every loaded
+// value by a 0/1 mask, as the first version did, made the compiler wait for each block's loads BEFORE the previous
+// block's MFMAs: nothing overlapped inside a wave.)  Columns past ka / nb read column 0 instead: their products land in
+// output elements wgrad_store never writes.  Only the < RB rows left at the end of a wave's slice take masked loads.
+template <int MT>
+__device__ __forceinline__ void wgrad_tile(const WgradJob& jb, const WgradArgs& a, int tile, int slice, int m, float* red) {
+  constexpr int NT = 2, TK = 32 * MT, TN = 32 * NT, U = 4, RB = 2 * U;
+  const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(wave_id());
   const int i = lane & 31, h = lane >> 5;
   const int tk = tile / jb.tiles_n, tn = tile - tk * jb.tiles_n;
   const int k0 = tk * TK, n0 = tn * TN;
-  const float* A = jb.A + m * jb.a_mstride;
-  const float* B = jb.B + m * jb.b_mstride;
   const long long r_begin = ((long long)slice * 4 + w) * a.rows_per_wave;
   const long long r_end = min(a.rows, r_begin + a.rows_per_wave);
+  const int lda = jb.lda, ldb = jb.ldb;
+
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int x = 0; x < MT; ++x)
@@ -453,23 +408,92 @@ __device__ __forceinline__ void wgrad_tile_bf(const WgradJob& jb, const WgradArg
     for (int y = 0; y < NT; ++y)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
-  const float* pa[MT]; const float* pb[NT];                      // job 0: every column is real (ka = nb = 256)
+
+  unsigned oa[MT], ob[NT];                            // byte offsets; lane half h takes the odd row of each pair
 #pragma unroll
-  for (int x = 0; x < MT; ++x) pa[x] = A + k0 + 32 * x + i;
+  for (int x = 0; x < MT; ++x) { const int c = k0 + 32 * x + i; oa[x] = 4u * (unsigned)((c < jb.ka ? c : 0) + h * lda); }
 #pragma unroll
-  for (int y = 0; y < NT; ++y) pb[y] = B + n0 + 32 * y + i;
-  auto load = [&](long long rb, float (&av)[MT][8], float (&bv)[NT][8]) {
+  for (int y = 0; y < NT; ++y) { const int c = n0 + 32 * y + i; ob[y] = 4u * (unsigned)((c < jb.nb ? c : 0) + h * ldb); }
+
+  auto mma = [&](float (&av)[U][MT], float (&bv)[U][NT]) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      long long row = rb + 8 * h + j;
-      const float rv = row < r_end ? 1.f : 0.f;
-      row = row < r_end ? row : r_begin;
+    for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int x = 0; x < MT; ++x) av[x][j] = pa[x][row * jb.lda] * rv;
+      for (int x = 0; x < MT; ++x)
 #pragma unroll
-      for (int y = 0; y < NT; ++y) bv[y][j] = pb[y][row * jb.ldb] * rv;
-    }
+        for (int y = 0; y < NT; ++y)
+          acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][x], bv[u][y], acc[x][y], 0, 0, 0);
   };
+  if (r_begin < r_end) {
+    const int nrows = (int)(r_end - r_begin), nblk = nrows / RB, tail = nrows - nblk * RB;
+    const auto ra = slice_rsrc(jb.A + m * jb.a_mstride + r_begin * lda, nrows, lda);
+    const auto rb = slice_rsrc(jb.B + m * jb.b_mstride + r_begin * ldb, nrows, ldb);
+    const unsigned sa = 4u * lda, sb = 4u * ldb;      // row pitch in bytes
+    auto load = [&](unsigned row, float (&av)[U][MT], float (&bv)[U][NT]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int x = 0; x < MT; ++x) av[u][x] = buf_ld(ra, oa[x], (row + 2 * u) * sa);
+#pragma unroll
+        for (int y = 0; y < NT; ++y) bv[u][y] = buf_ld(rb, ob[y], (row + 2 * u) * sb);
+      }
+    };
+    float a0[U][MT], b0[U][NT], a1[U][MT], b1[U][NT];
+    // Straight-line body (no branch between a block's loads and the previous block's MFMAs, or the compiler's vmcnt
+    // bookkeeping merges the two paths and waits for the NEW loads): the last pass re-loads block nblk - 1, unused if nblk is even.
+    if (nblk > 0) load(0, a0, b0);
+    for (int blk = 0; blk + 1 < nblk; blk += 2) {
+      load((blk + 1) * RB, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(min(blk + 2, nblk - 1) * RB, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nblk & 1) mma(a0, b0);
+    if (tail > 0) {                                   // rows [nblk * RB, nrows) of the slice: masked lanes re-read its first row
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool ok = 2 * u + h < tail;
+#pragma unroll
+        for (int x = 0; x < MT; ++x) { const float v = buf_ld(ra, ok ? oa[x] + 2 * u * sa : oa[x] - h * sa, nblk * RB * sa); a0[u][x] = ok ? v : 0.f; }
+#pragma unroll
+        for (int y = 0; y < NT; ++y) { const float v = buf_ld(rb, ok ? ob[y] + 2 * u * sb : ob[y] - h * sb, nblk * RB * sb); b0[u][y] = ok ? v : 0.f; }
+      }
+      mma(a0, b0);
+    }
+  }
+  wgrad_store<MT, NT>(jb, a, acc, k0, n0, slice, m, red);
+}
+
+// Split-precision form of the 256 x 256 job (dW2 = h1^T dz2, 86 % of the weight-gradient FLOPs): the contraction runs over
+// batch ROWS, so a lane's A / B fragment of v_mfma_f32_32x32x16_bf16 is eight consecutive rows of one column -- eight
+// coalesced scalar loads (a wave instruction = 2 rows x 128 bytes), split into NPL bf16 terms in registers, then the
+// (i + j < NPL) products.  Same work split, addressing, LDS reduction and slab output as wgrad_tile<2>; row blocks of 16.
+template <int NPL>
+__device__ __forceinline__ void wgrad_tile_bf(const WgradJob& jb, const WgradArgs& a, int tile, int slice, int m, float* red) {
+  constexpr int MT = 2, NT = 2, TK = 64, TN = 64, RB = 16;
+  const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(wave_id());
+  const int i = lane & 31, h = lane >> 5;
+  const int tk = tile / jb.tiles_n, tn = tile - tk * jb.tiles_n;
+  const int k0 = tk * TK, n0 = tn * TN;
+  const long long r_begin = ((long long)slice * 4 + w) * a.rows_per_wave;
+  const long long r_end = min(a.rows, r_begin + a.rows_per_wave);
+  const int lda = jb.lda, ldb = jb.ldb;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int x = 0; x < MT; ++x)
+#pragma unroll
+    for (int y = 0; y < NT; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  unsigned oa[MT], ob[NT];                                       // byte offsets; job 0: every column is real (ka = nb = 256)
+#pragma unroll
+  for (int x = 0; x < MT; ++x) oa[x] = 4u * (unsigned)(k0 + 32 * x + i + 8 * h * lda);
+#pragma unroll
+  for (int y = 0; y < NT; ++y) ob[y] = 4u * (unsigned)(n0 + 32 * y + i + 8 * h * ldb);
   auto pack = [&](const float (&v)[8], bf16x8 (&f)[NPL]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -496,39 +520,47 @@ __device__ __forceinline__ void wgrad_tile_bf(const WgradJob& jb, const WgradArg
             acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[x][q], bfr[y][d - q], acc[x][y], 0, 0, 0);
   };
   if (r_begin < r_end) {
-    float a0[MT][8], b0[NT][8], a1[MT][8], b1[NT][8];
-    load(r_begin, a0, b0);
-    for (long long rb = r_begin; rb < r_end; rb += 32) {
-      if (rb + 16 < r_end) load(rb + 16, a1, b1);
-      mma(a0, b0);
-      if (rb + 16 < r_end) {
-        if (rb + 32 < r_end) load(rb + 32, a0, b0);
-        mma(a1, b1);
+    const int nrows = (int)(r_end - r_begin), nblk = nrows / RB, tail = nrows - nblk * RB;
+    const auto ra = slice_rsrc(jb.A + m * jb.a_mstride + r_begin * lda, nrows, lda);
+    const auto rb = slice_rsrc(jb.B + m * jb.b_mstride + r_begin * ldb, nrows, ldb);
+    const unsigned sa = 4u * lda, sb = 4u * ldb;
+    auto load = [&](unsigned row, float (&av)[MT][8], float (&bv)[NT][8]) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int x = 0; x < MT; ++x) av[x][j] = buf_ld(ra, oa[x], (row + j) * sa);
+#pragma unroll
+        for (int y = 0; y < NT; ++y) bv[y][j] = buf_ld(rb, ob[y], (row + j) * sb);
       }
+    };
+    float a0[MT][8], b0[NT][8], a1[MT][8], b1[NT][8];
+    // Straight-line body (no branch between a block's loads and the previous block's MFMAs, or the compiler's vmcnt
+    // bookkeeping merges the two paths and waits for the NEW loads): the last pass re-loads block nblk - 1, unused if nblk is even.
+    if (nblk > 0) load(0, a0, b0);
+    for (int blk = 0; blk + 1 < nblk; blk += 2) {
+      load((blk + 1) * RB, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(min(blk + 2, nblk - 1) * RB, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nblk & 1) mma(a0, b0);
+    if (tail > 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = 8 * h + j < tail;
+#pragma unroll
+        for (int x = 0; x < MT; ++x) { const float v = buf_ld(ra, ok ? oa[x] + j * sa : oa[x] - 8 * h * sa, nblk * RB * sa); a0[x][j] = ok ? v : 0.f; }
+#pragma unroll
+        for (int y = 0; y < NT; ++y) { const float v = buf_ld(rb, ok ? ob[y] + j * sb : ob[y] - 8 * h * sb, nblk * RB * sb); b0[y][j] = ok ? v : 0.f; }
+      }
+      mma(a0, b0);
     }
   }
-  float* mine = red + (w & 1) * (TK * TN);
-  auto sweep = [&](bool add) {
-#pragma unroll
-    for (int x = 0; x < MT; ++x)
-#pragma unroll
-      for (int y = 0; y < NT; ++y)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kk = 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
-          float* p = mine + kk * TN + 32 * y + i;
-          *p = add ? *p + acc[x][y][r] : acc[x][y][r];
-        }
-  };
-  if (w < 2) sweep(false);
-  __syncthreads();
-  if (w >= 2) sweep(true);
-  __syncthreads();
-  float* slab = a.slabs + (long long)slice * a.slab_stride + jb.out_off + m * a.out_mstride;
-  for (int idx = threadIdx.x; idx < TK * TN; idx += NTHREADS) {
-    const int kk = idx / TN, nn = idx - kk * TN;
-    slab[wide_idx(k0 + kk, n0 + nn)] = red[idx] + red[TK * TN + idx];
-  }
+  wgrad_store<MT, NT>(jb, a, acc, k0, n0, slice, m, red);
 }
 
 template <int NPL>
@@ -567,18 +599,21 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
     once = true;
   }
   long long rpw = cdiv(a.rows, (long long)4 * a.nsplit);
-  a.rows_per_wave = (rpw + 1) & ~1LL;
+  a.rows_per_wave = (rpw + 15) & ~15LL;               // whole 8- / 16-row blocks for every wave but the last one with work
+  for (int k = 0; k < 3; ++k)                         // a wave addresses its row slice through 32-bit buffer offsets
+    if (a.rows_per_wave * (long long)std::max(a.job[k].lda, a.job[k].ldb) * 4 >= (1LL << 31))
+      return fail(MOBODY_E_ARG, "launch_wgrad: row slice too large for 32-bit offsets (raise nsplit)");
   a.job[0].tiles_n = (a.job[0].nb + 63) / 64; a.job[0].ntiles = ((a.job[0].ka + 63) / 64) * a.job[0].tiles_n;
   for (int k = 1; k < 3; ++k) { a.job[k].tiles_n = (a.job[k].nb + 63) / 64; a.job[k].ntiles = ((a.job[k].ka + 31) / 32) * a.job[k].tiles_n; }
   a.tiles_total = a.job[0].ntiles + a.job[1].ntiles + a.job[2].ntiles;
   const int sm = a.nsplit * a.members;
   const int blocks = 8 * ((sm + 7) / 8) * a.tiles_total;
   ProfScope prof(PROF_WGRAD, st);
-  // Split-precision job 0 -- only in the plain bf16 mode: splitting the operands in registers costs ~6 VALU instructions per
-  // value and term, which at two / three terms eats what the faster MFMAs give (measured per step at c2: 0.078 ms fp32,
-  // 0.078 bf16x2, 0.082 bf16x3, 0.053 bf16); MOBODY_WGRAD_BF=1 forces it for every mode, =0 disables it (tuning aids).
+  // Split-precision job 0 in every bf16 mode (the operand split costs ~6 VALU instructions per value and term; with the
+  // unmasked scalar-addressed row loop that still leaves a gain: per step at c2 0.058 ms fp32 job -> 0.052 bf16x3,
+  // 0.044 bf16x2); MOBODY_WGRAD_BF=0 keeps the job in fp32 (tuning aid).
   static const int bf_force = [] { const char* e = getenv("MOBODY_WGRAD_BF"); return e ? atoi(e) : -1; }();
-  const bool use_bf = bf_force == 1 ? a.prec != 0 : bf_force == 0 ? false : a.prec == 1;
+  const bool use_bf = bf_force == 0 ? false : a.prec != 0;
   if (use_bf && a.job[0].ka == HID && a.job[0].nb == HID && a.job[0].wide) {
     static bool once_bf = false;
     if (!once_bf) {

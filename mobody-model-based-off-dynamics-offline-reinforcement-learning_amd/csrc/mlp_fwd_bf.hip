@@ -21,6 +21,7 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
   const bf16x8* w2b = reinterpret_cast<const bf16x8*>(a.w2_planes + m * a.planes_ms);
   const float* w3 = a.w3 + m * a.sw3;
   const float* b3 = a.b3 + m * a.sb3;
+  TR(0);
   WideRing ring;
   wide_prefetch(w1, a.Kp1, ring);
   int c0 = 0;
@@ -33,6 +34,7 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
   }
   tile_zero_cols(Xs, c0, a.Kp1, TB);
   lds_barrier();
+  TR(1);
   if (a.save_x != nullptr && (m == 0 || a.x_ms != 0)) {
     const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
     float* sx = a.save_x + m * a.x_ms;
@@ -51,6 +53,7 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
                                        if (h1 != nullptr && (!decltype(guarded)::value || row < rows_here)) h1[row * HID + col] = y;
                                      },
                                      [&] { bf_prefetch<NPL>(w2b, bring); }, mask1, full, mg);
+  TR(2);
   auto save_h2 = [=](auto guarded, int row, int col, float y) {
     if (h2 != nullptr && (!decltype(guarded)::value || row < rows_here)) h2[row * HID + col] = y;
   };
@@ -70,11 +73,13 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
       narrow_prefetch<NT>(w3, 16 * NT, br);
       bias = b3[mycol < a.nout ? mycol : 0];
     }, mask2, full, mg);
+    TR(4);
     narrow_run<TB / 16, NT>(Xs, br, [&](int row, int col, float v) { emit(row, col, v, bias); });
   } else {
     bf_layer<ACT, MT, NPL>(Xs, Ps, TB, w2b, a.b2 + m * a.sb2, bring, save_h2, [] {}, mask2, full, mg);
     narrow_layer(Xs, w3, HID, a.Np3, [&](int row, int col, float v) { emit(row, col, v, b3[col < a.nout ? col : 0]); }, TB);
   }
+  TR(5);
 }
 
 // one or two independent networks per launch (blockIdx.y < members_a -> net a), as k_mlp3_fwd2

@@ -1,48 +1,51 @@
-"""Micro-benchmark of the split-precision forward (mobody_mlp3_forward_bf) against the fp32 forward: twin-Q at a few row
-counts, every mode, accuracy against the fp32 kernel's output."""
-import ctypes as C
+"""Micro-benchmark of the fused MLP forward (mobody_mlp3_forward) in every MFMA mode: twin-Q at a few row counts, with and
+without the saved activations (x, h1, h2) the weight-gradient kernel reads, accuracy against the fp32 kernel's output.
+    python tools/micro_fwd_bf.py [ROWS ...]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
 import torch
 import golden_util as gu
 from mobody_amd import _lib, ops, packing
+from mobody_amd._lib import ptr
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
 S, A = 17, 6
 pa, pq, _ = gu.policy_params(1, S, A)
 qb = packing.pack_mlp(pq, S + A, 1, dev, prefixes=["network1.", "network2."])
-planes = torch.zeros(2 * 3 * 256 * 256, dtype=torch.bfloat16, device=dev)
-vp = C.c_void_p
-lib.mobody_mlp_w2_planes.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp]
-lib.mobody_mlp3_forward_bf.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int64, C.c_int, C.c_float, vp, vp]
-assert lib.mobody_mlp_w2_planes(S + A, 1, 2, qb.data_ptr(), planes.data_ptr(), _lib.cur_stream()) == 0
+qT = ops.mlp_transpose(qb, S + A, 1, 2)
+L = _lib.mlp_layout(S + A, 1, 2)
 
 
-def timeit(fn, reps=50):
-    for _ in range(5):
+def timeit(fn, reps=200):
+    for _ in range(10):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()                     # graph replay: the kernels back to back, no host launch gaps
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 
 
 for rows in [int(x) for x in sys.argv[1:]] or (2560, 10240, 40960):
     s = torch.randn(rows, S, device=dev); a = torch.rand(rows, A, device=dev)
-    ref = ops.mlp3_forward(qb, S + A, 1, 2, s, a)
-    t32 = timeit(lambda: ops.mlp3_forward(qb, S + A, 1, 2, s, a))
-    line = f"rows {rows:6d}: f32 {t32:7.1f} us"
-    for prec in (1, 2, 3):
-        out = torch.empty(2, rows, 1, device=dev)
-        f = lambda: lib.mobody_mlp3_forward_bf(qb.data_ptr(), planes.data_ptr(), prec, S + A, 1, 2, s.data_ptr(), S, a.data_ptr(), A,
-                                              rows, 0, 1.0, out.data_ptr(), _lib.cur_stream())
-        assert f() == 0, lib.mobody_last_error()
-        torch.cuda.synchronize()
+    out = torch.empty(2, rows, 1, device=dev)
+    sx = torch.empty(rows, L.Kp1, device=dev); sh1 = torch.empty(2, rows, 256, device=dev); sh2 = torch.empty(2, rows, 256, device=dev)
+
+    def fwd(prec, save):
+        rc = lib.mobody_mlp3_forward(ptr(qb), ptr(qT), prec, S + A, 1, 2, ptr(s), S, ptr(a), A, rows, 0, 1.0, ptr(out),
+                                     ptr(sx if save else None), ptr(sh1 if save else None), ptr(sh2 if save else None), _lib.cur_stream())
+        assert rc == 0, lib.mobody_last_error()
+
+    fwd(0, False); torch.cuda.synchronize(); ref = out.clone()
+    line = f"rows {rows:6d}:"
+    for prec, name in enumerate(("f32", "bf16", "bf16x2", "bf16x3")):
+        fwd(prec, False); torch.cuda.synchronize()
         err = float((out - ref).abs().max() / ref.abs().max())
-        line += f" | prec{prec} {timeit(f):7.1f} us err {err:.1e}"
-    print(line, " RG", os.environ.get("MOBODY_BF_RG", "2"))
+        line += f" | {name} {timeit(lambda: fwd(prec, False)):6.1f} us, saving {timeit(lambda: fwd(prec, True)):6.1f} us, err {err:.1e}"
+    print(line)

@@ -9,7 +9,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "
 import numpy as np, torch
 import golden_util as gu
 from mobody_amd import ops, packing, _lib
-from test_hip_train import Engine
+from mobody_amd.engine import Engine
 
 dev = torch.device("cuda:0")
 S, A = 17, 6
@@ -18,7 +18,7 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 10240
 Nt = N * 4 // 5
 pa, pq, _ = gu.policy_params(1, S, A)
 eng = Engine(S, A, pa, pq, dev)
-cfg = gu.policy_cfg(S, A)
+cfg = gu.policy_cfg(S, A, mfma=os.environ.get('MOBODY_MFMA', 'f32'))
 b = [torch.as_tensor(x, dtype=torch.float32).to(dev).contiguous() for x in gu.gi.batch(3, N, S, A)]
 dims, hyp = ops.train_dims(S, A, N, Nt), ops.hyper(cfg)
 ws = ops.train_workspace(dims, dev)
@@ -26,11 +26,11 @@ ws = ops.train_workspace(dims, dev)
 
 def run():
     if mode == "fwd":
-        ops.mlp3_forward(eng.q, S + A, 1, 2, b[0], b[1], save=True)
+        ops.mlp3_forward(eng.q, S + A, 1, 2, b[0], b[1], save=True, blob_T=eng.q_T, precision=cfg['mfma'])
     elif mode == "critic":
-        ops.critic_step(dims, hyp, eng.actor, eng.q, eng.q_T, eng.qt, b, eng.gq, eng.loss[0:1], ws)
+        ops.critic_step(dims, hyp, eng.actor, eng.q, eng.q_T, eng.qt, b, eng.gq, eng.loss[0:1], ws, actor_blob_T=eng.actor_T, qtarg_blob_T=eng.qt_T)
     else:
-        ops.actor_forward(dims, hyp, eng.actor, eng.q, b[0], b[1], eng.stats, ws)
+        ops.actor_forward(dims, hyp, eng.actor, eng.q, b[0], b[1], eng.stats, ws, actor_blob_T=eng.actor_T, q_blob_T=eng.q_T)
         ops.actor_backward(dims, hyp, eng.actor, eng.actor_T, eng.q, eng.q_T, b[0], b[1], eng.stats, eng.ga, eng.loss[1:3], ws)
 
 
