@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MOBODY_ABI_VERSION 2
+#define MOBODY_ABI_VERSION 3
 #define MOBODY_E_ARG (-1)      /* bad argument (dims, null pointer, unsupported size) */
 #define MOBODY_E_LAUNCH (-2)   /* hipLaunch / runtime error */
 #define MOBODY_E_UNSUPPORTED (-3)
@@ -139,6 +139,20 @@ int mobody_dyn_step(const float* dyn_blob, const float* dyn_planes, int precisio
                     uint8_t* terminal, float* penalty, float* raw_reward, float* mean_out, float* workspace,
                     void* stream);
 
+/* ---- replay buffer views (used by the rollout below and by the gather / append entry points) ---- */
+typedef struct MobodyBufferView {   /* ReplayBuffer fields, algo/utils.py:19-23 */
+  const float* state; const float* action; const float* next_state; const float* reward; const float* not_done;
+  int64_t pitch;   /* floats between consecutive rows of EVERY field; 0 = five separate contiguous arrays
+                      ([rows][S], [rows][A], [rows][S], [rows], [rows]: the reference's shape) */
+} MobodyBufferView;
+/* Row-interleaved ring (what the mirror's ReplayBuffer allocates): one allocation of [rows][pitch] floats with
+ * pitch = mobody_ring_pitch(S, A) = 2S+A+2 rounded up to 16 floats (64 bytes), a row laid out
+ * state[S] | action[A] | next_state[S] | reward | not_done | zero padding, i.e. state = base, action = base + S,
+ * next_state = base + S + A, reward = base + 2S + A, not_done = reward + 1.  A view of exactly this shape with a
+ * 16-byte aligned base takes the kernels' fast path (a random row = whole aligned 64-byte sectors, 16-byte accesses);
+ * any other view (separate arrays, other pitches) is handled piecewise. */
+int64_t mobody_ring_pitch(int S, int A);
+
 /* The whole H-step imagined rollout on the device, appended to a ring buffer (MOBODY.rollout + add_batch,
  * mobody.py:596-657, utils.py:43-92): per step a = pi(s) (actor blob, mobody_mlp_layout(S, A, 1)), one fused ensemble
  * step with device-Philox noise / elite picks at call id call0 + t, the penalty filter (`penalty <= env_filter` when
@@ -151,9 +165,8 @@ int64_t mobody_rollout_workspace(int S, int A, int64_t B);
 int mobody_rollout(const float* dyn_blob, const float* dyn_planes, const float* actor_blob, const float* actor_blob_T,
                    int precision, int S, int A, int task, float max_action,
                    const float* init_obs, int64_t B, int H, const int32_t* elites, int n_elites, uint32_t seed, uint32_t call0,
-                   float penalty_coef, int use_penalty, int use_trg, float env_filter, int filter_bad_rollout, float* b_state,
-                   float* b_action, float* b_next_state, float* b_reward, float* b_not_done, int64_t cap, int64_t* ptr_size,
-                   float* workspace, void* stream);
+                   float penalty_coef, int use_penalty, int use_trg, float env_filter, int filter_bad_rollout,
+                   const MobodyBufferView* ring, int64_t cap, int64_t* ptr_size, float* workspace, void* stream);
 
 /* Termination predicate alone: done[B] (uint8) = terminal_fn(next_obs[B][S])  (terminal_funs.py:10-121). */
 int mobody_termination(int task, const float* next_obs, int64_t B, int S, uint8_t* done, void* stream);
@@ -186,10 +199,6 @@ int mobody_mlp3_forward(const float* blob, const float* blob_T, int precision, i
  * bf16 planes from the T blob (mobody_mlp_transpose builds them, the Adam kernels keep them current). */
 
 /* ---- replay gather / ring append ------------------------------------------------------- */
-typedef struct MobodyBufferView {   /* ReplayBuffer fields, algo/utils.py:19-23 */
-  const float* state; const float* action; const float* next_state; const float* reward; const float* not_done;
-} MobodyBufferView;
-
 /* Concatenate rows idx_k of up to three buffers (src | tar | fake order, mobody.py:525-529)
  * into one minibatch: state[N][S] action[N][A] next_state[N][S] reward[N] not_done[N]. */
 int mobody_gather_batch(const MobodyBufferView* bufs, const int32_t* const* idx, const int64_t* counts, int nbuf,
@@ -206,14 +215,14 @@ int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64_t* counts,
                             const int64_t* const* sizes, float* state, float* action, float* next_state,
                             float* reward, float* not_done, void* stream);
 
-/* Append the rows with keep[i] != 0 (NULL = all), in order, to a ring buffer of `cap` rows at
- * *ptr_size (device int64[2] = {ptr, size}), reproducing add_batch's single-wrap arithmetic
- * (utils.py:43-92); not_done = 1 - terminal.  `scan_ws` needs (M + 1040) int32.  Two launches: a block scan whose last
- * block commits the new {ptr, size}, and the row scatter. */
-int mobody_ring_append(float* b_state, float* b_action, float* b_next_state, float* b_reward, float* b_not_done,
-                       int64_t cap, int64_t* ptr_size, int S, int A, const float* obs, const float* act,
-                       const float* next_obs, const float* reward, const uint8_t* terminal, const uint8_t* keep,
-                       int64_t M, int32_t* scan_ws, void* stream);
+/* Append the rows with keep[i] != 0 (NULL = all), in order, to the ring `ring` of `cap` rows (written through the
+ * view's pointers) at *ptr_size (device int64[2] = {ptr, size}), reproducing add_batch's single-wrap arithmetic
+ * (utils.py:43-92); not_done = 1 - terminal; the row-interleaved ring also gets its row padding zeroed.
+ * `scan_ws` needs (M + 1040) int32.  Two launches: a block scan whose last block commits the new {ptr, size}, and the
+ * row scatter. */
+int mobody_ring_append(const MobodyBufferView* ring, int64_t cap, int64_t* ptr_size, int S, int A, const float* obs,
+                       const float* act, const float* next_obs, const float* reward, const uint8_t* terminal,
+                       const uint8_t* keep, int64_t M, int32_t* scan_ws, void* stream);
 
 /* ---- training step --------------------------------------------------------------------- */
 typedef struct MobodyTrainDims {

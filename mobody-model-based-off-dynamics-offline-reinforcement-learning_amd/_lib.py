@@ -42,7 +42,7 @@ class MobodyPretrainLayout(C.Structure):
 
 
 class MobodyBufferView(C.Structure):
-    _fields_ = [("state", vp), ("action", vp), ("next_state", vp), ("reward", vp), ("not_done", vp)]
+    _fields_ = [("state", vp), ("action", vp), ("next_state", vp), ("reward", vp), ("not_done", vp), ("pitch", i64)]
 
 
 class MobodyTrainDims(C.Structure):
@@ -77,7 +77,7 @@ PROTOTYPES = {
                                   u32, u32, f32, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mobody_rollout_workspace": (i64, [C.c_int, C.c_int, i64]),
     "mobody_rollout": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, f32, vp, i64, C.c_int, C.POINTER(i32), C.c_int, u32, u32, f32,
-                                 C.c_int, C.c_int, f32, C.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp]),
+                                 C.c_int, C.c_int, f32, C.c_int, C.POINTER(MobodyBufferView), i64, vp, vp, vp]),
     "mobody_termination": (C.c_int, [C.c_int, vp, i64, C.c_int, vp, vp]),
     "mobody_rollout_mask": (C.c_int, [vp, vp, vp, f32, C.c_int, i64, vp, vp, vp]),
     "mobody_sample_indices": (C.c_int, [u32, u32, vp, i64, i64, vp, vp, vp]),
@@ -88,8 +88,9 @@ PROTOTYPES = {
                                       C.c_int, vp, vp, vp, vp, vp, vp]),
     "mobody_gather_batch_rng": (C.c_int, [C.POINTER(MobodyBufferView), C.POINTER(i64), C.c_int, C.c_int, C.c_int,
                                           C.POINTER(u32), C.POINTER(i64), vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp]),
-    "mobody_ring_append": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, vp,
+    "mobody_ring_append": (C.c_int, [C.POINTER(MobodyBufferView), i64, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, vp,
                                      vp]),
+    "mobody_ring_pitch": (i64, [C.c_int, C.c_int]),
     "mobody_train_workspace": (i64, [C.POINTER(MobodyTrainDims)]),
     "mobody_critic_step": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                      vp, vp, vp, vp, vp, vp, C.c_int, vp]),
@@ -143,7 +144,7 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.mobody_abi_version() != 2:
+    if lib.mobody_abi_version() != 3:
         raise ImportError("libmobody_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -321,8 +321,11 @@ class MOBODY(object):
         n, chunk = src_replay_buffer.size, 1 << 16                                       # reference sweeps 1000 rows at a time
         for i in range(0, n, chunk):
             j = min(n, i + chunk)
-            self._dara_delta(src_replay_buffer.state[i:j], src_replay_buffer.action[i:j], src_replay_buffer.next_state[i:j],
-                             src_replay_buffer.reward[i:j], self.config["penalty_coef"])
+            rb = src_replay_buffer                         # the fields are column views of the row-interleaved store
+            r = rb.reward[i:j].contiguous()
+            self._dara_delta(rb.state[i:j].contiguous(), rb.action[i:j].contiguous(), rb.next_state[i:j].contiguous(), r,
+                             self.config["penalty_coef"])
+            rb.reward[i:j].copy_(r)
 
     # ------------------------------------------------------------------ rollouts
     def rollout(self, init_obss, rollout_length, use_trg=True):

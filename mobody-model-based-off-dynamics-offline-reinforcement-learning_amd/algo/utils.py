@@ -1,9 +1,11 @@
 """Device-resident ReplayBuffer -- host-side mirror of the reference's `algo/utils.py:13-193`.
 
 Same constructor, attributes (`state action next_state reward not_done size ptr max_size device`)
-and methods (`add add_batch sample sample_all convert_D4RL`), but the SoA storage lives in HBM and
-every row movement is a HIP kernel (gather: csrc/replay.hip k_gather; append: k_ring_scatter), so
-`sample()` costs no host gather and no H2D copy.  `ptr`/`size` are mirrored in a device int64[2]
+and methods (`add add_batch sample sample_all convert_D4RL`), but the storage lives in HBM as ONE
+row-interleaved array (`store[rows][pitch]`, a row = state | action | next_state | reward | not_done | padding to 64
+bytes; the five attributes are column views of it) and every row movement is a HIP kernel (gather: csrc/replay.hip
+k_gather; append: k_ring_scatter), so `sample()` costs no host gather and no H2D copy and a random row is three
+aligned 64-byte sectors instead of five scattered pieces.  `ptr`/`size` are mirrored in a device int64[2]
 word pair (`ptr_size`) that the append kernels update, and cached on the host.
 
 Index draws: `rng='numpy'` (default) consumes `np.random.randint(0, size, n)` exactly like
@@ -24,9 +26,8 @@ class ReplayBuffer(object):
         self.state_dim, self.action_dim = int(state_dim), int(action_dim)
         self.device = torch.device(device)
         assert self.device.type == "cuda", "the MI355X replay buffer is device resident (no CPU fallback)"
-        z = lambda n: torch.zeros((self.max_size, n), dtype=torch.float32, device=self.device)
-        self.state, self.action, self.next_state = z(state_dim), z(action_dim), z(state_dim)
-        self.reward, self.not_done = z(1), z(1)
+        self.pitch = ops.ring_pitch(self.state_dim, self.action_dim)
+        self._adopt(torch.zeros((self.max_size, self.pitch), dtype=torch.float32, device=self.device))
         self.ptr_size = torch.zeros(2, dtype=torch.int64, device=self.device)
         self._ptr = self._size = 0
         self.mobile = 0
@@ -55,8 +56,14 @@ class ReplayBuffer(object):
     def _pull(self):
         self._ptr, self._size = [int(x) for x in self.ptr_size.tolist()]
 
+    def _adopt(self, store):
+        """`store` [rows][pitch] becomes the storage; state / action / next_state / reward / not_done are views of it."""
+        self.store = store
+        self._view = ops.RingView(store, self.state_dim, self.action_dim)
+        self.state, self.action, self.next_state, self.reward, self.not_done = self._view.fields()
+
     def _fields(self):
-        return tuple(getattr(self, f) for f in FIELDS)
+        return self._view
 
     def _to_dev(self, x, cols=None, dtype=torch.float32):
         t = x if isinstance(x, torch.Tensor) else torch.as_tensor(np.asarray(x))
@@ -109,12 +116,15 @@ class ReplayBuffer(object):
 
     def convert_D4RL(self, dataset):
         """Adopt a D4RL-style dict (utils.py:173-193): the buffer becomes exactly the dataset."""
-        self.state = self._to_dev(dataset["observations"], self.state_dim)
-        self.action = self._to_dev(dataset["actions"], self.action_dim)
-        self.next_state = self._to_dev(dataset["next_observations"], self.state_dim)
-        self.reward = self._to_dev(dataset["rewards"], 1)
+        s = self._to_dev(dataset["observations"], self.state_dim)
+        store = torch.zeros((s.shape[0], self.pitch), dtype=torch.float32, device=self.device)
+        self._adopt(store)
+        self.state.copy_(s)
+        self.action.copy_(self._to_dev(dataset["actions"], self.action_dim))
+        self.next_state.copy_(self._to_dev(dataset["next_observations"], self.state_dim))
+        self.reward.copy_(self._to_dev(dataset["rewards"], 1))
         term = torch.as_tensor(np.asarray(dataset["terminals"])).reshape(-1, 1).to(torch.float32)
-        self.not_done = (1.0 - term).to(self.device).contiguous()
+        self.not_done.copy_((1.0 - term).to(self.device))
         # the reference keeps max_size and ptr as they were: a later add()/add_batch() that runs past the adopted rows
         # is a shape error there; here add_batch checks the row count before launching (see _rows_ok)
         self.size = self.state.shape[0]
@@ -137,5 +147,5 @@ class ReplayBuffer(object):
 
     def sample_all(self, cuda=True):
         n = self.size
-        out = tuple(getattr(self, f)[:n] for f in FIELDS)
+        out = tuple(getattr(self, f)[:n].contiguous() for f in FIELDS)     # copies, like the reference's FloatTensor(...)
         return out if cuda else tuple(t.cpu() for t in out)

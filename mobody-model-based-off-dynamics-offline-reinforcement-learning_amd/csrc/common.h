@@ -48,10 +48,9 @@ struct ProfScope {
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // ring append (replay.hip): block scan (+ commit of the new {ptr, size} by the last block) and the row scatter
-int launch_ring_append(float* b_state, float* b_action, float* b_next_state, float* b_reward, float* b_not_done, long long cap,
-                       long long* ptr_size, int S, int A, const float* obs, const float* act, const float* next_obs,
-                       const float* reward, const uint8_t* terminal, const uint8_t* keep, long long M, int32_t* scan_ws,
-                       hipStream_t st);
+int launch_ring_append(const MobodyBufferView& ring, long long cap, long long* ptr_size, int S, int A, const float* obs,
+                       const float* act, const float* next_obs, const float* reward, const uint8_t* terminal,
+                       const uint8_t* keep, long long M, int32_t* scan_ws, hipStream_t st);
 __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // device-side view of one packed MLP (member 0 pointers + strides), built from MobodyMlpLayout

@@ -465,12 +465,12 @@ extern "C" int mobody_rollout(const float* dyn_blob, const float* dyn_planes, co
                               int precision, int S, int A, int task, float max_action,
                               const float* init_obs, int64_t B, int H, const int32_t* elites, int n_elites, uint32_t seed,
                               uint32_t call0, float penalty_coef, int use_penalty, int use_trg, float env_filter,
-                              int filter_bad_rollout, float* b_state, float* b_action, float* b_next_state, float* b_reward,
-                              float* b_not_done, int64_t cap, int64_t* ptr_size, float* workspace, void* stream) {
+                              int filter_bad_rollout, const MobodyBufferView* ring, int64_t cap, int64_t* ptr_size, float* workspace,
+                              void* stream) {
   MB_REQUIRE(B >= 0 && H >= 0, "mobody_rollout: bad sizes");
   if (B == 0 || H == 0) return 0;
   MB_REQUIRE(B <= cap, "mobody_rollout: %lld rows per step overflow the ring of %lld twice", (long long)B, (long long)cap);
-  MB_REQUIRE(dyn_blob && actor_blob && init_obs && elites && b_state && b_action && b_next_state && b_reward && b_not_done &&
+  MB_REQUIRE(dyn_blob && actor_blob && init_obs && elites && ring && ring->state && ring->action && ring->next_state && ring->reward && ring->not_done &&
                  ptr_size && workspace, "mobody_rollout: null pointer");
   MobodyMlpLayout La;
   int rc = mobody_mlp_layout(S, A, 1, &La);
@@ -504,7 +504,7 @@ extern "C" int mobody_rollout(const float* dyn_blob, const float* dyn_planes, co
                        call0 + (uint32_t)t, penalty_coef, use_penalty, use_trg, nxt, w.reward, w.terminal, w.penalty, nullptr, nullptr,
                        w.dyn, w.keep, w.alive, env_filter, filter_bad_rollout, stream);
     if (rc) return rc;
-    rc = launch_ring_append(b_state, b_action, b_next_state, b_reward, b_not_done, cap, (long long*)ptr_size, S, A, obs, w.act, nxt,
+    rc = launch_ring_append(*ring, cap, (long long*)ptr_size, S, A, obs, w.act, nxt,
                             w.reward, w.terminal, w.keep, B, w.scan, st);
     if (rc) return rc;
     obs = nxt;

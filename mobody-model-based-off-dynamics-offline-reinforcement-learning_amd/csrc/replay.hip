@@ -1,19 +1,33 @@
 // Device-resident replay data movement (all HBM-bound, 4*(2S+A+2) bytes per row each way):
-//   k_gather        minibatch assembly: rows idx_k of up to three SoA buffers, concatenated
+//   k_gather        minibatch assembly: rows idx_k of up to three buffers, concatenated
 //                   src | tar | fake          (ReplayBuffer.sample utils.py:127-148 + torch.cat mobody.py:516-529)
 //   ring append     stream-compact the kept rows (penalty filter mobody.py:468,648-653) and write them
 //                   into the ring with add_batch's single-wrap arithmetic (utils.py:43-92);
-//                   three small kernels: per-block scan, scan of block totals, scatter (+ ptr/size update).
+//                   two kernels: block scan (+ ptr/size commit) and the row scatter.
+// Storage layouts (MobodyBufferView.pitch): the ROW-INTERLEAVED ring ("packed": one row = state | action | next_state |
+// reward | not_done contiguous, rows `pitch` floats apart, pitch a multiple of 16 floats = 64 bytes) is what the mirror's
+// ReplayBuffer allocates -- a random row is then three aligned 64-byte sectors (S=17, A=6: 168 of 192 bytes useful) read or
+// written with 16-byte accesses; five separate arrays (pitch 0, the reference's field-per-array shape) cost five random
+// pieces of 4..68 bytes per row, ~2.8x the useful bytes at S=17.  Both kernels stage 16 rows per workgroup in LDS so the
+// batch side (contiguous [N][S] / [N][A] / [N] arrays) is read and written fully coalesced.
 #include "common.h"
 #include "rng.h"
 
 namespace mobody {
 
+constexpr int ROWS_WG = 16;
+
+__host__ __device__ inline bool view_packed(const MobodyBufferView& b, int S, int A) {
+  return b.pitch > 0 && b.pitch % 16 == 0 && b.pitch >= 2LL * S + A + 2 && (reinterpret_cast<uintptr_t>(b.state) & 15) == 0 &&
+         b.action == b.state + S && b.next_state == b.action + A && b.reward == b.next_state + S && b.not_done == b.reward + 1;
+}
+
 struct GatherArgs {
   MobodyBufferView bufs[3];
+  int packed[3];            // view_packed(bufs[k])
   const int32_t* idx[3];    // explicit row indices, or null -> drawn on the fly from the device generator
   long long start[4];       // row offsets of each source inside the output, start[nbuf] = N
-  int nbuf, S, A;
+  int nbuf, S, A, WS;       // WS = staged floats per row (2S+A+2 rounded up to 4)
   float *state, *action, *next_state, *reward, *not_done;
   // device-RNG mode (idx[k] == null): index i of source k = philox(seed[k], STREAM_SAMPLE, call)[i] * size >> 32,
   // call = (counter ? counter[0] : 0) + call_offset[k], size read from the device word size[k][0]
@@ -23,13 +37,24 @@ struct GatherArgs {
   const long long* size[3];
 };
 
-// One ROW per 16-lane group (16 rows per workgroup): the source index -- an explicit index or one Philox draw -- is formed
-// once per row by the group's first lane and broadcast, then the group's lanes copy the five SoA pieces of the row with
-// consecutive addresses.  (The first version ran one thread per FLOAT: an integer division and a full Philox-10 per
-// element, 42 per row at S=17/A=6 -- the kernel was ALU bound at 1.0 TB/s.)
+// field block f of `rows` staged rows -> contiguous output rows (all 256 threads, consecutive addresses)
+__device__ __forceinline__ void stage_to_batch(const float* stage, int WS, int off, int n, int rows, float* out) {
+  for (int e = threadIdx.x; e < rows * n; e += 256) {
+    const int r = e / n, c = e - r * n;
+    out[e] = stage[r * WS + off + c];
+  }
+}
+
+// 16 ROWS per workgroup, one row per 16-lane group: the source index -- an explicit index or one Philox draw -- is formed
+// once per row by the group's first lane and broadcast; the group copies its row into LDS (packed ring: 16-byte loads of
+// the whole row; separate arrays: the five pieces), then the workgroup writes the five output blocks coalesced.
+// 64-row workgroups (four rows per group in flight) were measured slower: 230 us against 172 us per million rows.
+// (The first version ran one thread per FLOAT: an integer division and a full Philox-10 per element.)
 __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
-  const int lane = threadIdx.x & 15;
-  const long long row = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+  extern __shared__ __attribute__((aligned(16))) float stage[];     // [16][WS]
+  const int lane = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long long row0 = (long long)blockIdx.x * ROWS_WG;
+  const long long row = row0 + g;
   const long long N = a.start[a.nbuf];
   const bool ok = row < N;
   const long long r = ok ? row : 0;
@@ -46,26 +71,50 @@ __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
       src = rng_index_at(a.seed[k], STREAM_SAMPLE, call, (uint64_t)(r - a.start[k]), (uint32_t)(sz > 0 ? sz : 1));
     }
   }
-  src = __shfl(src, threadIdx.x & 48, 64);            // lane 0 of this 16-lane group (groups are 16-aligned inside the wave)
-  if (!ok) return;
-  const int S = a.S, A = a.A;
-  const MobodyBufferView& b = a.bufs[k];
-  for (int c = lane; c < S; c += 16) {
-    a.state[row * S + c] = b.state[src * S + c];
-    a.next_state[row * S + c] = b.next_state[src * S + c];
+  src = __shfl(src, threadIdx.x & 48, 64);
+  const int S = a.S, A = a.A, WS = a.WS;
+  float* mine = stage + g * WS;
+  if (ok) {
+    const MobodyBufferView& b = a.bufs[k];
+    if (a.packed[k]) {
+      const float4* rp = reinterpret_cast<const float4*>(b.state + src * b.pitch);
+      for (int q = lane; 4 * q < WS; q += 16) reinterpret_cast<float4*>(mine)[q] = rp[q];
+    } else {
+      const long long ps = b.pitch ? b.pitch : S, pa = b.pitch ? b.pitch : A, p1 = b.pitch ? b.pitch : 1;
+      for (int c = lane; c < S; c += 16) {
+        mine[c] = b.state[src * ps + c];
+        mine[S + A + c] = b.next_state[src * ps + c];
+      }
+      for (int c = lane; c < A; c += 16) mine[S + c] = b.action[src * pa + c];
+      if (lane == 0) mine[2 * S + A] = b.reward[src * p1];
+      if (lane == 1) mine[2 * S + A + 1] = b.not_done[src * p1];
+    }
   }
-  for (int c = lane; c < A; c += 16) a.action[row * A + c] = b.action[src * A + c];
-  if (lane == 0) a.reward[row] = b.reward[src];
-  if (lane == 1) a.not_done[row] = b.not_done[src];
+  __syncthreads();
+  const int rows = (int)min((long long)ROWS_WG, N - row0);
+  stage_to_batch(stage, WS, 0, S, rows, a.state + row0 * S);
+  stage_to_batch(stage, WS, S, A, rows, a.action + row0 * A);
+  stage_to_batch(stage, WS, S + A, S, rows, a.next_state + row0 * S);
+  stage_to_batch(stage, WS, 2 * S + A, 1, rows, a.reward + row0);
+  stage_to_batch(stage, WS, 2 * S + A + 1, 1, rows, a.not_done + row0);
+}
+
+static int launch_gather(const GatherArgs& a, long long N, hipStream_t st) {
+  const size_t lds = (size_t)ROWS_WG * a.WS * sizeof(float);
+  if (lds > 64 * 1024) return fail(MOBODY_E_ARG, "gather: rows of %d floats do not fit the LDS stage", a.WS);
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)cdiv(N, ROWS_WG)), dim3(256), lds, st, a);
+  MB_LAUNCH_OK("k_gather");
+  return 0;
 }
 
 // ---- ring append in two launches ------------------------------------------------------------------------------------
-//  k_scan_blocks  per-1024-row exclusive scan of the keep flags (pos[i]) and block totals (tops[b]); the LAST block to
-//                 finish (atomic ticket) sums the totals, snapshots the ring's old {ptr, size} into the workspace and
-//                 commits the new ones (add_batch's single-wrap arithmetic, utils.py:43-92) -- all integer, deterministic.
+//  k_scan_blocks  per-4096-row exclusive scan of the keep flags (pos[i]) and block totals (tops[b]); the LAST block to
+//                 finish (atomic ticket) turns the totals into their exclusive prefix, snapshots the ring's old {ptr, size}
+//                 into the workspace and commits the new ones (add_batch's single-wrap arithmetic, utils.py:43-92) -- all
+//                 integer, deterministic.
 //  k_ring_scatter one row per 16-lane group: destination = old ptr + (rows kept before this one), wrapped once.
 // Workspace (int32): pos[M] | tops[nblocks] | meta[8] = {ticket, K, old_ptr lo/hi, ...}.  The ticket is left at 0.
-constexpr int SCAN_BLOCK = 1024;
+constexpr int SCAN_BLOCK = 4096;                    // rows per scan block
 
 struct ScanArgs {
   const uint8_t* keep;
@@ -75,39 +124,54 @@ struct ScanArgs {
   int nblocks;
 };
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_blocks(ScanArgs a) {
-  __shared__ int32_t sm[SCAN_BLOCK];
-  __shared__ int last;
-  const long long i = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  const int32_t f = (i < a.M) ? (a.keep ? (a.keep[i] != 0) : 1) : 0;
-  sm[threadIdx.x] = f;
-  __syncthreads();
-  for (int o = 1; o < SCAN_BLOCK; o <<= 1) {        // Hillis-Steele inclusive scan
-    const int32_t v = (threadIdx.x >= (unsigned)o) ? sm[threadIdx.x - o] : 0;
-    __syncthreads();
-    sm[threadIdx.x] += v;
-    __syncthreads();
+// inclusive scan of one int per thread over the 1024-thread workgroup: wave scans by shuffles, the 16 wave totals in LDS
+__device__ __forceinline__ int32_t block_scan_1024(int32_t v, int32_t* wtot) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t u = __shfl_up(v, o, 64);
+    if (lane >= o) v += u;
   }
-  if (i < a.M) a.pos[i] = sm[threadIdx.x] - f;
-  if (threadIdx.x == SCAN_BLOCK - 1) {
-    a.tops[blockIdx.x] = sm[threadIdx.x];
+  __syncthreads();                                   // wtot free (previous use read)
+  if (lane == 63) wtot[w] = v;
+  __syncthreads();
+  int32_t before = 0;
+#pragma unroll
+  for (int k = 0; k < 15; ++k) before += (k < w) ? wtot[k] : 0;
+  return v + before;
+}
+
+// 1024 threads x 4 consecutive rows = one 4096-row scan block (one ticket atomic per block: ~40 ns each on one address,
+// so a million rows cost 10 us of tickets instead of the 40 us a 1024-row block took)
+__global__ __launch_bounds__(1024) void k_scan_blocks(ScanArgs a) {
+  __shared__ int32_t wtot[16];
+  __shared__ int last;
+  const long long i0 = (long long)blockIdx.x * SCAN_BLOCK + 4 * threadIdx.x;
+  int32_t f[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) f[j] = (i0 + j < a.M) ? (a.keep ? (a.keep[i0 + j] != 0) : 1) : 0;
+  const int32_t mine4 = f[0] + f[1] + f[2] + f[3];
+  const int32_t inc = block_scan_1024(mine4, wtot);
+  int32_t run = inc - mine4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (i0 + j < a.M) a.pos[i0 + j] = run;
+    run += f[j];
+  }
+  if (threadIdx.x == 1023) {
+    a.tops[blockIdx.x] = inc;
     __threadfence();                                 // the total is visible before the ticket is taken
     last = atomicAdd(&a.meta[0], 1) == a.nblocks - 1;
   }
   __syncthreads();
   if (!last) return;
   __threadfence();
-  int32_t s = 0;                                     // this block finished last: K = sum of the block totals
-  for (int b = threadIdx.x; b < a.nblocks; b += SCAN_BLOCK) s += a.tops[b];
-  __syncthreads();
-  sm[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = SCAN_BLOCK / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const long long K = sm[0];
+  // this block finished last: exclusive scan of the block totals in place (nblocks <= 1024 = one per thread), K = their sum
+  const int32_t mine = (int)threadIdx.x < a.nblocks ? a.tops[threadIdx.x] : 0;
+  const int32_t pre = block_scan_1024(mine, wtot);
+  if ((int)threadIdx.x < a.nblocks) a.tops[threadIdx.x] = pre - mine;
+  if (threadIdx.x == 1023) {
+    const long long K = pre;
     const long long ptr = a.ptr_size[0], size = a.ptr_size[1];
     a.meta[1] = (int32_t)K;
     a.meta[2] = (int32_t)(ptr & 0xFFFFFFFFLL); a.meta[3] = (int32_t)(ptr >> 32);
@@ -123,9 +187,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_blocks(ScanArgs a) {
 }
 
 struct RingArgs {
-  float *b_state, *b_action, *b_next_state, *b_reward, *b_not_done;
+  MobodyBufferView ring;                                       // written
+  int packed;
   long long cap;
-  int S, A;
+  int S, A, WS;                                                // WS = staged floats per row: the pitch (packed) or 2S+A+2 up to 4
   const float *obs, *act, *next_obs, *reward;
   const uint8_t *terminal, *keep;
   long long M;
@@ -138,90 +203,138 @@ __device__ __forceinline__ long long ring_dst(long long j, long long ptr, long l
   return j < used ? ptr + j : j - used;                        // second segment starts at 0 (:82-87)
 }
 
-__global__ __launch_bounds__(256) void k_ring_scatter(RingArgs a) {
-  __shared__ int32_t sm[4];
-  const int lane = threadIdx.x & 15;
-  const long long row0 = (long long)blockIdx.x * 16;           // 16 rows per workgroup, all inside one scan block
-  const int sb = (int)(row0 / SCAN_BLOCK);
-  int32_t part = 0;                                            // rows kept in the scan blocks before this one
-  for (int b = threadIdx.x; b < sb; b += 256) part += a.tops[b];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = part;
-  __syncthreads();
-  const long long base = (long long)sm[0] + sm[1] + sm[2] + sm[3];
-  const long long i = row0 + (threadIdx.x >> 4);
-  if (i >= a.M || (a.keep && !a.keep[i])) return;
-  const long long K = a.meta[1];
-  const long long ptr = ((long long)(uint32_t)a.meta[2]) | ((long long)a.meta[3] << 32);
-  const long long d = ring_dst(base + a.pos[i], ptr, K, a.cap);
-  const int S = a.S, A = a.A;
-  for (int c = lane; c < S; c += 16) {
-    a.b_state[d * S + c] = a.obs[i * S + c];
-    a.b_next_state[d * S + c] = a.next_obs[i * S + c];
+// contiguous batch rows -> field block of the LDS stage (all 256 threads, consecutive addresses)
+__device__ __forceinline__ void batch_to_stage(float* stage, int WS, int off, int n, int rows, const float* in) {
+  for (int e = threadIdx.x; e < rows * n; e += 256) {
+    const int r = e / n, c = e - r * n;
+    stage[r * WS + off + c] = in[e];
   }
-  for (int c = lane; c < A; c += 16) a.b_action[d * A + c] = a.act[i * A + c];
-  if (lane == 0) a.b_reward[d] = a.reward[i];
-  if (lane == 1) a.b_not_done[d] = 1.f - (float)(a.terminal[i] != 0);
 }
 
-int launch_ring_append(float* b_state, float* b_action, float* b_next_state, float* b_reward, float* b_not_done, long long cap,
-                       long long* ptr_size, int S, int A, const float* obs, const float* act, const float* next_obs,
-                       const float* reward, const uint8_t* terminal, const uint8_t* keep, long long M, int32_t* scan_ws,
-                       hipStream_t st) {
+// P = rows per 16-lane group (16 * P rows per workgroup): 4 for long batches of short rows -- 1M-row appends 195 -> ~120 us.
+template <int P>
+__global__ __launch_bounds__(256) void k_ring_scatter(RingArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float stage[];     // [16 * P][WS]
+  const int lane = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long long row0 = (long long)blockIdx.x * (ROWS_WG * P);     // all inside one scan block (4096 % (16 P) == 0)
+  const long long base = a.tops[row0 / SCAN_BLOCK];                  // rows kept in the scan blocks before this one
+  const int S = a.S, A = a.A, WS = a.WS, W = 2 * S + A + 2;
+  const int rows = (int)min((long long)ROWS_WG * P, a.M - row0);
+  batch_to_stage(stage, WS, 0, S, rows, a.obs + row0 * S);
+  batch_to_stage(stage, WS, S, A, rows, a.act + row0 * A);
+  batch_to_stage(stage, WS, S + A, S, rows, a.next_obs + row0 * S);
+  batch_to_stage(stage, WS, 2 * S + A, 1, rows, a.reward + row0);
+  if ((int)threadIdx.x < rows) stage[threadIdx.x * WS + 2 * S + A + 1] = 1.f - (float)(a.terminal[row0 + threadIdx.x] != 0);
+  for (int e = threadIdx.x; e < rows * (WS - W); e += 256) {   // padding of the row: zeros (whole sectors are written)
+    const int r = e / (WS - W), c = e - r * (WS - W);
+    stage[r * WS + W + c] = 0.f;
+  }
+  __syncthreads();
+  const long long K = a.meta[1];
+  const long long ptr = ((long long)(uint32_t)a.meta[2]) | ((long long)a.meta[3] << 32);
+  const MobodyBufferView& b = a.ring;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const long long i = row0 + ROWS_WG * p + g;
+    if (i >= a.M || (a.keep && !a.keep[i])) continue;
+    const long long d = ring_dst(base + a.pos[i], ptr, K, a.cap);
+    const float* mine = stage + (ROWS_WG * p + g) * WS;
+    if (a.packed) {
+      float4* rp = reinterpret_cast<float4*>(const_cast<float*>(b.state) + d * b.pitch);
+      for (int q = lane; 4 * q < WS; q += 16) rp[q] = reinterpret_cast<const float4*>(mine)[q];
+    } else {
+      const long long ps = b.pitch ? b.pitch : S, pa = b.pitch ? b.pitch : A, p1 = b.pitch ? b.pitch : 1;
+      float* bs = const_cast<float*>(b.state); float* bn = const_cast<float*>(b.next_state); float* ba = const_cast<float*>(b.action);
+      for (int c = lane; c < S; c += 16) {
+        bs[d * ps + c] = mine[c];
+        bn[d * ps + c] = mine[S + A + c];
+      }
+      for (int c = lane; c < A; c += 16) ba[d * pa + c] = mine[S + c];
+      if (lane == 0) const_cast<float*>(b.reward)[d * p1] = mine[2 * S + A];
+      if (lane == 1) const_cast<float*>(b.not_done)[d * p1] = mine[2 * S + A + 1];
+    }
+  }
+}
+
+int launch_ring_append(const MobodyBufferView& ring, long long cap, long long* ptr_size, int S, int A, const float* obs,
+                       const float* act, const float* next_obs, const float* reward, const uint8_t* terminal,
+                       const uint8_t* keep, long long M, int32_t* scan_ws, hipStream_t st) {
   const int nblocks = (int)cdiv(M, SCAN_BLOCK);
   int32_t* pos = scan_ws;
   int32_t* tops = scan_ws + M;
   int32_t* meta = tops + nblocks;
   ScanArgs sa{keep, M, cap, pos, tops, meta, ptr_size, nblocks};
   if (hipMemsetAsync(meta, 0, 8 * sizeof(int32_t), st) != hipSuccess) return fail(MOBODY_E_LAUNCH, "ring append: memset failed");
-  hipLaunchKernelGGL(k_scan_blocks, dim3(nblocks), dim3(SCAN_BLOCK), 0, st, sa);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(nblocks), dim3(1024), 0, st, sa);
   MB_LAUNCH_OK("k_scan_blocks");
-  RingArgs a{b_state, b_action, b_next_state, b_reward, b_not_done, cap, S, A, obs, act, next_obs, reward, terminal, keep, M,
-             pos, tops, meta};
-  hipLaunchKernelGGL(k_ring_scatter, dim3((unsigned)cdiv(M, 16)), dim3(256), 0, st, a);
+  const int packed = view_packed(ring, S, A);
+  const int WS = packed ? (int)ring.pitch : (2 * S + A + 2 + 3) & ~3;
+  const int P = M >= 32768 && WS <= 64 ? 4 : 1;
+  const size_t lds = (size_t)ROWS_WG * P * WS * sizeof(float);
+  if (lds > 64 * 1024) return fail(MOBODY_E_ARG, "ring append: rows of %d floats do not fit the LDS stage", WS);
+  RingArgs a{ring, packed, cap, S, A, WS, obs, act, next_obs, reward, terminal, keep, M, pos, tops, meta};
+  if (P == 4) hipLaunchKernelGGL(k_ring_scatter<4>, dim3((unsigned)cdiv(M, ROWS_WG * 4)), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(k_ring_scatter<1>, dim3((unsigned)cdiv(M, ROWS_WG)), dim3(256), lds, st, a);
   MB_LAUNCH_OK("k_ring_scatter");
+  return 0;
+}
+
+static int check_view(const char* who, const MobodyBufferView& b, int S, int A) {
+  MB_REQUIRE(b.state && b.action && b.next_state && b.reward && b.not_done, "%s: null pointer in a buffer view", who);
+  MB_REQUIRE(b.pitch == 0 || b.pitch >= S, "%s: pitch %lld smaller than a state row", who, (long long)b.pitch);
   return 0;
 }
 
 }  // namespace mobody
 using namespace mobody;
 
+extern "C" int64_t mobody_ring_pitch(int S, int A) { return S >= 1 && A >= 1 ? ((2LL * S + A + 2 + 15) / 16) * 16 : -1; }
+
+static int gather_common(const char* who, GatherArgs& a, const MobodyBufferView* bufs, const int64_t* counts, int nbuf, int S, int A,
+                         float* state, float* action, float* next_state, float* reward, float* not_done, long long& N) {
+  MB_REQUIRE(S >= 1 && A >= 1, "%s: bad dims", who);
+  N = 0;
+  for (int k = 0; k < nbuf; ++k) {
+    MB_REQUIRE(counts[k] >= 0, "%s: negative count", who);
+    if (counts[k] > 0) { int rc = check_view(who, bufs[k], S, A); if (rc) return rc; }
+    a.bufs[k] = bufs[k]; a.packed[k] = view_packed(bufs[k], S, A); a.start[k] = N; N += counts[k];
+  }
+  a.start[nbuf] = N; a.nbuf = nbuf; a.S = S; a.A = A; a.WS = (2 * S + A + 2 + 3) & ~3;
+  if (N == 0) return 0;
+  MB_REQUIRE(state && action && next_state && reward && not_done, "%s: null output", who);
+  a.state = state; a.action = action; a.next_state = next_state; a.reward = reward; a.not_done = not_done;
+  return 0;
+}
+
 extern "C" int mobody_gather_batch(const MobodyBufferView* bufs, const int32_t* const* idx, const int64_t* counts,
                                    int nbuf, int S, int A, float* state, float* action, float* next_state,
                                    float* reward, float* not_done, void* stream) {
   MB_REQUIRE(bufs && idx && counts && nbuf >= 1 && nbuf <= 3, "mobody_gather_batch: need 1..3 source buffers");
-  MB_REQUIRE(S >= 1 && A >= 1, "mobody_gather_batch: bad dims");
   GatherArgs a{};
-  long long N = 0;
+  long long N;
+  int rc = gather_common("mobody_gather_batch", a, bufs, counts, nbuf, S, A, state, action, next_state, reward, not_done, N);
+  if (rc || N == 0) return rc;
   for (int k = 0; k < nbuf; ++k) {
-    MB_REQUIRE(counts[k] >= 0, "mobody_gather_batch: negative count");
-    MB_REQUIRE(counts[k] == 0 || (idx[k] && bufs[k].state && bufs[k].action && bufs[k].next_state && bufs[k].reward && bufs[k].not_done),
-               "mobody_gather_batch: null pointer in source %d", k);
-    a.bufs[k] = bufs[k]; a.idx[k] = idx[k]; a.start[k] = N; N += counts[k];
+    MB_REQUIRE(counts[k] == 0 || idx[k], "mobody_gather_batch: null index array of source %d", k);
+    a.idx[k] = idx[k];
   }
-  a.start[nbuf] = N; a.nbuf = nbuf; a.S = S; a.A = A;
-  if (N == 0) return 0;
-  MB_REQUIRE(state && action && next_state && reward && not_done, "mobody_gather_batch: null output");
-  a.state = state; a.action = action; a.next_state = next_state; a.reward = reward; a.not_done = not_done;
-  hipLaunchKernelGGL(k_gather, dim3((unsigned)cdiv(N, 16)), dim3(256), 0, as_stream(stream), a);
-  MB_LAUNCH_OK("k_gather");
-  return 0;
+  return launch_gather(a, N, as_stream(stream));
 }
 
-extern "C" int mobody_ring_append(float* b_state, float* b_action, float* b_next_state, float* b_reward,
-                                  float* b_not_done, int64_t cap, int64_t* ptr_size, int S, int A, const float* obs,
+extern "C" int mobody_ring_append(const MobodyBufferView* ring, int64_t cap, int64_t* ptr_size, int S, int A, const float* obs,
                                   const float* act, const float* next_obs, const float* reward,
                                   const uint8_t* terminal, const uint8_t* keep, int64_t M, int32_t* scan_ws,
                                   void* stream) {
   MB_REQUIRE(M >= 0 && cap >= 1, "mobody_ring_append: bad sizes");
   if (M == 0) return 0;
   MB_REQUIRE(M <= cap, "mobody_ring_append: batch of %lld rows overflows the ring of %lld twice (add_batch would raise)", (long long)M, (long long)cap);
-  MB_REQUIRE(M <= (int64_t)SCAN_BLOCK * SCAN_BLOCK, "mobody_ring_append: at most %d rows per call", SCAN_BLOCK * SCAN_BLOCK);
-  MB_REQUIRE(b_state && b_action && b_next_state && b_reward && b_not_done && ptr_size && obs && act && next_obs && reward &&
-                 terminal && scan_ws, "mobody_ring_append: null pointer");
-  return launch_ring_append(b_state, b_action, b_next_state, b_reward, b_not_done, cap, (long long*)ptr_size, S, A, obs, act,
-                            next_obs, reward, terminal, keep, M, scan_ws, as_stream(stream));
+  MB_REQUIRE(M <= (int64_t)SCAN_BLOCK * 1024, "mobody_ring_append: at most %d rows per call", SCAN_BLOCK * 1024);
+  MB_REQUIRE(ring && ptr_size && obs && act && next_obs && reward && terminal && scan_ws, "mobody_ring_append: null pointer");
+  MB_REQUIRE(S >= 1 && A >= 1, "mobody_ring_append: bad dims");
+  int rc = check_view("mobody_ring_append", *ring, S, A);
+  if (rc) return rc;
+  return launch_ring_append(*ring, cap, (long long*)ptr_size, S, A, obs, act, next_obs, reward, terminal, keep, M, scan_ws,
+                            as_stream(stream));
 }
 
 extern "C" int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64_t* counts, int nbuf, int S, int A,
@@ -229,21 +342,14 @@ extern "C" int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64
                                        const int64_t* const* sizes, float* state, float* action, float* next_state,
                                        float* reward, float* not_done, void* stream) {
   MB_REQUIRE(bufs && counts && seeds && call_offsets && sizes && nbuf >= 1 && nbuf <= 3, "mobody_gather_batch_rng: need 1..3 source buffers");
-  MB_REQUIRE(S >= 1 && A >= 1, "mobody_gather_batch_rng: bad dims");
   GatherArgs a{};
-  long long N = 0;
+  long long N;
+  int rc = gather_common("mobody_gather_batch_rng", a, bufs, counts, nbuf, S, A, state, action, next_state, reward, not_done, N);
+  if (rc || N == 0) return rc;
   for (int k = 0; k < nbuf; ++k) {
-    MB_REQUIRE(counts[k] >= 0, "mobody_gather_batch_rng: negative count");
-    MB_REQUIRE(counts[k] == 0 || (sizes[k] && bufs[k].state && bufs[k].action && bufs[k].next_state && bufs[k].reward && bufs[k].not_done),
-               "mobody_gather_batch_rng: null pointer in source %d", k);
-    a.bufs[k] = bufs[k]; a.idx[k] = nullptr; a.start[k] = N; N += counts[k];
-    a.seed[k] = seeds[k]; a.call_offset[k] = call_offsets[k]; a.size[k] = (const long long*)sizes[k];
+    MB_REQUIRE(counts[k] == 0 || sizes[k], "mobody_gather_batch_rng: null size word of source %d", k);
+    a.idx[k] = nullptr; a.seed[k] = seeds[k]; a.call_offset[k] = call_offsets[k]; a.size[k] = (const long long*)sizes[k];
   }
-  a.start[nbuf] = N; a.nbuf = nbuf; a.S = S; a.A = A; a.counter = (const long long*)counter;
-  if (N == 0) return 0;
-  MB_REQUIRE(state && action && next_state && reward && not_done, "mobody_gather_batch_rng: null output");
-  a.state = state; a.action = action; a.next_state = next_state; a.reward = reward; a.not_done = not_done;
-  hipLaunchKernelGGL(k_gather, dim3((unsigned)cdiv(N, 16)), dim3(256), 0, as_stream(stream), a);
-  MB_LAUNCH_OK("k_gather");
-  return 0;
+  a.counter = (const long long*)counter;
+  return launch_gather(a, N, as_stream(stream));
 }

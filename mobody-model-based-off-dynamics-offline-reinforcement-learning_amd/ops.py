@@ -203,12 +203,48 @@ def adam_polyak(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t, l
 # ------------------------------------------------------------------------------------------------
 # replay data movement
 # ------------------------------------------------------------------------------------------------
+class RingView:
+    """A row-interleaved replay ring: `store` is one [rows][pitch] fp32 tensor, a row = state | action | next_state | reward |
+    not_done | padding (include/mobody_hip.h, mobody_ring_pitch).  Iterating yields the five field views (strided)."""
+
+    def __init__(self, store, S, A):
+        assert store.is_contiguous() and store.dtype == torch.float32 and store.shape[1] >= 2 * S + A + 2
+        self.store, self.S, self.A = store, int(S), int(A)
+        self.device = store.device
+
+    def fields(self):
+        S, A, st = self.S, self.A, self.store
+        return st[:, :S], st[:, S:S + A], st[:, S + A:2 * S + A], st[:, 2 * S + A:2 * S + A + 1], st[:, 2 * S + A + 1:2 * S + A + 2]
+
+    def __iter__(self):
+        return iter(self.fields())
+
+    def __getitem__(self, k):
+        return self.fields()[k]
+
+
+def ring_pitch(S, A):
+    return int(load().mobody_ring_pitch(int(S), int(A)))
+
+
+def buffer_view(b):
+    """MobodyBufferView of a RingView or of a 5-tuple of separate contiguous tensors (state, action, next_state, reward, not_done)."""
+    if isinstance(b, RingView):
+        base, S, A = b.store.data_ptr(), b.S, b.A
+        return _lib.MobodyBufferView(base, base + 4 * S, base + 4 * (S + A), base + 4 * (2 * S + A), base + 4 * (2 * S + A + 1), b.store.shape[1])
+    return _lib.MobodyBufferView(*[ptr(t) for t in b], 0)
+
+
+def _view_device(b):
+    return b.device if isinstance(b, RingView) else b[0].device
+
+
 def gather_batch(buffers, indices, S, A, out=None):
-    """buffers: list of (state, action, next_state, reward, not_done) device tensors; indices: int32 device
+    """buffers: list of RingView or (state, action, next_state, reward, not_done) device tensors; indices: int32 device
     tensors. Returns the concatenated minibatch (state[N,S], action[N,A], next_state[N,S], reward[N,1], not_done[N,1])."""
     n = len(buffers)
-    dev = buffers[0][0].device
-    views = (_lib.MobodyBufferView * n)(*[_lib.MobodyBufferView(*[ptr(t) for t in b]) for b in buffers])
+    dev = _view_device(buffers[0])
+    views = (_lib.MobodyBufferView * n)(*[buffer_view(b) for b in buffers])
     idx = [i.to(device=dev, dtype=torch.int32).contiguous() for i in indices]
     iptr = (C.c_void_p * n)(*[ptr(i) if i.numel() else None for i in idx])
     cnt = (C.c_int64 * n)(*[i.numel() for i in idx])
@@ -222,13 +258,13 @@ def gather_batch(buffers, indices, S, A, out=None):
 
 
 def ring_append(buf, cap, ptr_size, S, A, obs, act, next_obs, reward, terminal, keep=None):
-    """buf = (state, action, next_state, reward, not_done) ring tensors; ptr_size int64[2] device tensor."""
+    """buf = RingView or (state, action, next_state, reward, not_done) ring tensors; ptr_size int64[2] device tensor."""
     M = obs.shape[0]
     if M == 0:
         return
     dev = obs.device
     scan = torch.empty(M + 1040, dtype=torch.int32, device=dev)
-    check(load().mobody_ring_append(*[ptr(t) for t in buf], cap, ptr(ptr_size), S, A, ptr(obs), ptr(act), ptr(next_obs),
+    check(load().mobody_ring_append(C.byref(buffer_view(buf)), cap, ptr(ptr_size), S, A, ptr(obs), ptr(act), ptr(next_obs),
                                     ptr(reward), ptr(terminal), ptr(keep), M, ptr(scan), cur_stream()),
           "mobody_ring_append")
 
@@ -279,7 +315,7 @@ def gather_batch_rng(buffers, counts, seeds, call_offsets, counter, sizes, S, A,
     """Gather with device-drawn indices: buffers = list of 5-tuples, sizes = list of device int64[1] views,
     counter = device int64[1] or None.  `out` = (state, action, next_state, reward, not_done) destination tensors."""
     n = len(buffers)
-    views = (_lib.MobodyBufferView * n)(*[_lib.MobodyBufferView(*[ptr(t) for t in b]) for b in buffers])
+    views = (_lib.MobodyBufferView * n)(*[buffer_view(b) for b in buffers])
     cnt = (C.c_int64 * n)(*[int(c) for c in counts])
     sd = (C.c_uint32 * n)(*[int(s) & 0xFFFFFFFF for s in seeds])
     off = (C.c_int64 * n)(*[int(o) for o in call_offsets])
@@ -412,6 +448,6 @@ def rollout(dyn_blob, actor_blob, S, A, task_id, max_action, init_obs, H, elites
     check(load().mobody_rollout(ptr(dyn_blob), ptr(dyn_planes), ptr(actor_blob), ptr(actor_blob_T), prec_id(precision), S, A,
                                 task_id, float(max_action), ptr(_f32(init_obs)), B, int(H),
                                 el, len(elites), seed, call0, float(penalty_coef), int(bool(use_penalty)), int(bool(use_trg)),
-                                float(env_filter), int(bool(filter_bad_rollout)), *[ptr(t) for t in buf], cap, ptr(ptr_size),
+                                float(env_filter), int(bool(filter_bad_rollout)), C.byref(buffer_view(buf)), cap, ptr(ptr_size),
                                 ptr(ws), cur_stream()), "mobody_rollout")
     return ws

@@ -214,7 +214,7 @@ def test_million_row_ring_wraps_and_gather_draws(dev):
     Philox draws equal the CPU twin and fetch exactly those rows (bit exact)."""
     from mobody_amd import ops
     cap, S, A, M = 1000000, 17, 6, 260000
-    buf = tuple(torch.zeros(cap, n, device=dev) for n in (S, A, S, 1, 1))
+    buf = ops.RingView(torch.zeros(cap, ops.ring_pitch(S, A), device=dev), S, A)      # the layout ReplayBuffer allocates
     ps = torch.zeros(2, dtype=torch.int64, device=dev)
     want = np.zeros(cap, np.float32)
     ptr = size = 0
@@ -231,7 +231,7 @@ def test_million_row_ring_wraps_and_gather_draws(dev):
             want[dst:dst + ln] = ids[src:src + ln]
         assert ps.cpu().tolist() == [ptr, size], c
     assert size == cap
-    for t in buf[:4]:
+    for t in buf.fields()[:4]:
         got = t.cpu().numpy()
         assert (got == want[:, None]).all()
     n = 16384

@@ -14,12 +14,28 @@ def dev():
     return torch.device("cuda:0")
 
 
-def test_ring_append_matches_reference_add_batch(dev):
+LAYOUTS = ("ring", "arrays")        # the row-interleaved ring the mirror allocates / five separate arrays (the reference's shape)
+
+
+def make_buf(layout, rows, S, A, dev, fill=None):
+    """An empty (or `fill`ed: five [rows][n] arrays) replay storage of either layout; both index / iterate as the five fields."""
+    from mobody_amd import ops
+    if layout == "arrays":
+        return tuple(torch.zeros(rows, n, device=dev) if fill is None else torch.from_numpy(fill[k]).to(dev).contiguous()
+                     for k, n in enumerate((S, A, S, 1, 1)))
+    v = ops.RingView(torch.zeros(rows, ops.ring_pitch(S, A), device=dev), S, A)
+    if fill is not None:
+        for t, x in zip(v, fill):
+            t.copy_(torch.from_numpy(x))
+    return v
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_ring_append_matches_reference_add_batch(dev, layout):
     from mobody_amd import ops
     g = gu.load("g8_replay")
     cap, S, A = 50, 5, 2
-    buf = (torch.zeros(cap, S, device=dev), torch.zeros(cap, A, device=dev), torch.zeros(cap, S, device=dev),
-           torch.zeros(cap, 1, device=dev), torch.zeros(cap, 1, device=dev))
+    buf = make_buf(layout, cap, S, A, dev)
     ps = torch.zeros(2, dtype=torch.int64, device=dev)
     names = ("state", "action", "next_state", "reward", "not_done")
     for ci, (M, want_ptr, want_size) in enumerate(g["log"]):
@@ -35,11 +51,12 @@ def test_ring_append_matches_reference_add_batch(dev):
         assert (t.cpu().numpy() == g["sample_" + k]).all(), k
 
 
-def test_ring_append_with_filter_and_concat_gather(dev):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_ring_append_with_filter_and_concat_gather(dev, layout):
     from mobody_amd import ops
     rng = np.random.default_rng(0)
     cap, S, A, M = 3000, 17, 6, 2500
-    buf = tuple(torch.zeros(cap, n, device=dev) for n in (S, A, S, 1, 1))
+    buf = make_buf(layout, cap, S, A, dev)
     ps = torch.tensor([2000, 2400], dtype=torch.int64, device=dev)
     obs, act, nxt = (rng.standard_normal((M, n)).astype(np.float32) for n in (S, A, S))
     rew = rng.standard_normal((M, 1)).astype(np.float32)
@@ -59,8 +76,9 @@ def test_ring_append_with_filter_and_concat_gather(dev):
     for dst, src, ln in segs:
         assert (got[dst:dst + ln] == want[dst:dst + ln]).all()
     assert (buf[4].cpu().numpy()[segs[0][0]:segs[0][0] + segs[0][2], 0] == 1.0 - term[keep.astype(bool)][:segs[0][2], 0]).all()
-    # three-way concatenated gather
-    b2 = tuple(td(rng.standard_normal((100, n)).astype(np.float32)) for n in (S, A, S, 1, 1))
+    # three-way concatenated gather, the middle source in the OTHER layout
+    b2 = make_buf("arrays" if layout == "ring" else "ring", 100, S, A, dev,
+                  fill=[rng.standard_normal((100, n)).astype(np.float32) for n in (S, A, S, 1, 1)])
     i1, i2, i3 = rng.integers(0, cap, 33), rng.integers(0, 100, 20), rng.integers(0, cap, 0)
     out = ops.gather_batch([buf, b2, buf], [td(i1), td(i2), td(i3)], S, A)
     for k in range(5):
@@ -86,7 +104,8 @@ def test_replay_buffer_mirror_add_batch_sep_equals_add_batch(dev):
         assert torch.equal(x, y)
 
 
-def test_ring_append_random_sequences_vs_reference_arithmetic(dev):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_ring_append_random_sequences_vs_reference_arithmetic(dev, layout):
     """Random append sequences (sizes up to the capacity, random keep masks, hits of the exact-wrap cases) against a
     NumPy replay of add_batch's single-wrap slice arithmetic (utils.py:43-92) on the kept rows."""
     from mobody_amd import ops
@@ -94,7 +113,7 @@ def test_ring_append_random_sequences_vs_reference_arithmetic(dev):
     S, A = 3, 2
     for case in range(25):
         cap = int(rng.integers(5, 200))
-        buf = tuple(torch.zeros(cap, n, device=dev) for n in (S, A, S, 1, 1))
+        buf = make_buf(layout, cap, S, A, dev)
         ps = torch.zeros(2, dtype=torch.int64, device=dev)
         ref = [np.zeros((cap, n), np.float32) for n in (S, A, S, 1, 1)]
         ptr = size = 0
@@ -125,7 +144,8 @@ def test_ring_append_random_sequences_vs_reference_arithmetic(dev):
                 assert (t.cpu().numpy() == want).all(), (case, step)
 
 
-def test_on_device_rollout_equals_the_step_by_step_composition(dev):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_on_device_rollout_equals_the_step_by_step_composition(dev, layout):
     """`mobody_rollout` (H steps, fused mask, two-launch append) == the same rollout assembled from the stand-alone entry
     points (actor forward -> mobody_dyn_step -> mobody_rollout_mask -> mobody_ring_append), bit for bit, into a ring that
     wraps (cap < rows appended)."""
@@ -141,8 +161,7 @@ def test_on_device_rollout_equals_the_step_by_step_composition(dev):
     elites = (0, 2, 3, 5, 6)
 
     def ring():
-        z = lambda n: torch.zeros(cap, n, device=dev)
-        return (z(S), z(A), z(S), z(1), z(1)), torch.tensor([100, 100], dtype=torch.int64, device=dev)
+        return make_buf(layout, cap, S, A, dev), torch.tensor([100, 100], dtype=torch.int64, device=dev)
 
     buf1, ps1 = ring()
     ops.rollout(dyn, actor, S, A, 4, 1.0, init, H, elites, 21, 7, 0.1, True, True, 0.5, True, buf1, cap, ps1)
@@ -159,3 +178,33 @@ def test_on_device_rollout_equals_the_step_by_step_composition(dev):
     assert ps1.tolist() == ps2.tolist() and ps1.tolist()[1] == cap          # the ring filled up and wrapped
     for a, b in zip(buf1, buf2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("S,A", [(17, 6), (111, 8), (45, 24), (3, 1)])
+def test_ring_layout_row_padding_and_wide_rows(dev, S, A):
+    """The row-interleaved ring at every task width (ant rows span 15 sectors): append + gather round trip equals the
+    separate-array path bit for bit, and the padding floats of every written row are zero."""
+    from mobody_amd import ops
+    rng = np.random.default_rng(S)
+    cap, M = 400, 333
+    bufs = [make_buf(l, cap, S, A, dev) for l in LAYOUTS]
+    bufs[0].store.fill_(7.0)                                  # stale contents: written rows must come out clean
+    rows = [rng.standard_normal((M, n)).astype(np.float32) for n in (S, A, S, 1)]
+    term = (rng.uniform(size=(M, 1)) > 0.5).astype(np.uint8)
+    keep = (rng.uniform(size=M) > 0.25).astype(np.uint8)
+    td = lambda x: torch.from_numpy(x).to(dev).contiguous()
+    pss = []
+    for b in bufs:
+        ps = torch.tensor([350, 360], dtype=torch.int64, device=dev)
+        ops.ring_append(b, cap, ps, S, A, td(rows[0]), td(rows[1]), td(rows[2]), td(rows[3]), td(term), td(keep))
+        pss.append(ps.tolist())
+    assert pss[0] == pss[1]
+    K = int(keep.sum())
+    written = [(350 + j) % cap if 350 + j < cap else j - (cap - 350) for j in range(K)]
+    W = 2 * S + A + 2
+    st = bufs[0].store.cpu().numpy()
+    assert (st[written, W:] == 0).all() and (st[written, :W] != 7.0).all()
+    idx = td(np.asarray(written + written[::-1], np.int32))
+    o1, o2 = ops.gather_batch([bufs[0]], [idx], S, A), ops.gather_batch([bufs[1]], [idx], S, A)
+    for x, y in zip(o1, o2):
+        assert torch.equal(x, y)
