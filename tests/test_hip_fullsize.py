@@ -37,7 +37,11 @@ def grads_close(got, want, scale):
     d = np.abs(got - want)
     tight = d <= 1e-5 * scale + 1e-5 * np.abs(want)
     loose = int((~tight).sum())                  # one flipped unit moves one bias entry / one weight column
-    assert loose <= max(8, got.size // 1000), f"{loose} of {got.size} entries beyond 1e-5 of the gradient scale"
+    from mobody_amd import ops
+    # with the suite forced to the bench's default mode (MOBODY_MFMA=bf16x3) the three-term products sit ~1e-7 from the
+    # fp32 ones and flip a few more units at their ReLU kink (C4: 77 entries where fp32 has 60): 0.15 % instead of 0.1 %
+    per = 1000 if ops.default_mfma() == "f32" else 667
+    assert loose <= max(8, got.size // per), f"{loose} of {got.size} entries beyond 1e-5 of the gradient scale"
     assert d.max() <= 2e-3 * scale, f"max deviation {d.max() / scale:.2e} of the gradient scale"
 
 CONFIGS = {"C2": (17, 6, 10240, 8192), "C3": (17, 6, 40960, 32768), "C4": (111, 8, 20480, 16384),
@@ -122,9 +126,9 @@ def test_train_step_full_size_is_deterministic_and_shards_linearly(name, dev):
         b = [torch.as_tensor(x[sel], dtype=torch.float32).to(dev).contiguous() for x in batch]
         d = ops.train_dims(S, A, N // 2, Nt // 2, N, Nt)
         ws = ops.train_workspace(d, dev)
-        ops.critic_step(d, hyp, e.actor, e.q, e.q_T, e.qt, b, e.gq, e.loss[0:1], ws)
+        ops.critic_step(d, hyp, e.actor, e.q, e.q_T, e.qt, b, e.gq, e.loss[0:1], ws, actor_blob_T=e.actor_T, qtarg_blob_T=e.qt_T)
         gq += e.gq
-        ops.actor_forward(d, hyp, e.actor, e.q, b[0], b[1], e.stats, ws)
+        ops.actor_forward(d, hyp, e.actor, e.q, b[0], b[1], e.stats, ws, actor_blob_T=e.actor_T, q_blob_T=e.q_T)
         stats += e.stats
         parts.append((e, b, d, ws))
     for e, b, d, ws in parts:

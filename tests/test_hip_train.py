@@ -121,9 +121,9 @@ def test_data_parallel_shards_sum_to_full_batch(dev):
         b = [torch.as_tensor(x[hsel], dtype=torch.float32).to(dev).contiguous() for x in batch]
         d = ops.train_dims(S, A, N // 2, Nt // 2, N, Nt)
         ws = ops.train_workspace(d, dev)
-        ops.critic_step(d, hyp, e.actor, e.q, e.q_T, e.qt, b, e.gq, e.loss[0:1], ws)
+        ops.critic_step(d, hyp, e.actor, e.q, e.q_T, e.qt, b, e.gq, e.loss[0:1], ws, actor_blob_T=e.actor_T, qtarg_blob_T=e.qt_T)
         gq += e.gq
-        ops.actor_forward(d, hyp, e.actor, e.q, b[0], b[1], e.stats, ws)
+        ops.actor_forward(d, hyp, e.actor, e.q, b[0], b[1], e.stats, ws, actor_blob_T=e.actor_T, q_blob_T=e.q_T)
         stats += e.stats
         parts.append((e, b, d, ws))
     for e, b, d, ws in parts:           # "all-reduced" statistics, then the backward halves
@@ -181,8 +181,8 @@ def test_fused_update_is_bit_identical_to_step_plus_adam(S, A, N, Nt, dev):
     ws = ops.train_workspace(dims, dev)
     for step in (1, 2, 3):
         ref.step(batch, Nt, cfg)
-        ops.critic_update(dims, hyp, fus.actor, fus.q, fus.q_T, fus.qt, b, fus.mq, fus.vq, step, cfg["critic_lr"], fus.loss[0:1], ws)
-        ops.actor_forward(dims, hyp, fus.actor, fus.q, b[0], b[1], fus.stats, ws)
+        ops.critic_update(dims, hyp, fus.actor, fus.q, fus.q_T, fus.qt, b, fus.mq, fus.vq, step, cfg["critic_lr"], fus.loss[0:1], ws, actor_blob_T=fus.actor_T, qtarg_blob_T=fus.qt_T)
+        ops.actor_forward(dims, hyp, fus.actor, fus.q, b[0], b[1], fus.stats, ws, actor_blob_T=fus.actor_T, q_blob_T=fus.q_T)
         ops.actor_update(dims, hyp, fus.actor, fus.actor_T, fus.q, fus.q_T, b[0], b[1], fus.stats, fus.ma, fus.va, step,
                          cfg["actor_lr"], fus.loss[1:3], ws)
         torch.cuda.synchronize()
@@ -202,8 +202,8 @@ def test_policy_forward_riding_with_the_target_q_launch_is_bit_identical(dev):
     for ride in (False, True):
         e = Engine(S, A, pa, pq, dev)
         ws = ops.train_workspace(dims, dev)
-        ops.critic_step(dims, hyp, e.actor, e.q, e.q_T, e.qt, b, e.gq, e.loss[0:1], ws, policy_forward=ride)
-        ops.actor_forward(dims, hyp, e.actor, e.q, b[0], b[1], e.stats, ws, policy_ready=ride)
+        ops.critic_step(dims, hyp, e.actor, e.q, e.q_T, e.qt, b, e.gq, e.loss[0:1], ws, policy_forward=ride, actor_blob_T=e.actor_T, qtarg_blob_T=e.qt_T)
+        ops.actor_forward(dims, hyp, e.actor, e.q, b[0], b[1], e.stats, ws, policy_ready=ride, actor_blob_T=e.actor_T, q_blob_T=e.q_T)
         ops.actor_backward(dims, hyp, e.actor, e.actor_T, e.q, e.q_T, b[0], b[1], e.stats, e.ga, e.loss[1:3], ws)
         torch.cuda.synchronize()
         outs.append((e.gq.clone(), e.ga.clone(), e.loss.clone(), e.stats.clone()))
