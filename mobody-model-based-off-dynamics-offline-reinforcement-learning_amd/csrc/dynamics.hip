@@ -35,7 +35,8 @@ struct DynFwdArgs {
 constexpr long long DYN_PLANE_MEMBER = 3LL * HID * HID;                       // bf16 elements per (layer, member)
 __host__ __device__ inline long long dyn_planes_off(int layer, int member) { return ((long long)layer * NENS + member) * DYN_PLANE_MEMBER; }
 
-// NT3: 16-column tiles of the transition head handled by the K-split narrow layer (Np == 16*NT3), 0 = any width.
+// NT3: 16-column tiles of the transition head handled by the K-split narrow layer (Np == 16*NT3: 1, 2, 3 or 7), 0 = any width
+// (row-split narrow_layer: half of the waves idle on a 32-row tile).
 // NPL: 0 = exact fp32 MFMA; 1..3 = the two 256 x 256 layers (zs2, transition2) on the split-precision bf16 core.
 template <int MT, int NT3, int NPL>
 __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
@@ -133,9 +134,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
       narrow_prefetch<NT3>(Wp(MOBODY_DL_TR3), 16 * NT3, br);
       bias = b3[mycol < S ? mycol : 0];
     });
-    narrow_run<TB / 16, NT3>(Xs, br, [&](int row, int col, float v) {
-      if (row < rows_here && col < S) mean[row * S + col] = v + bias;
-    });
+    if constexpr (NT3 > 2) {                             // wide heads (pen 48, ant 112 columns): 32-row passes, bias by column
+      narrow_run_wide<TB / 16, NT3>(Xs, br, [&](int row, int col, float v) {
+        if (row < rows_here && col < S) mean[row * S + col] = v + b3[col];
+      });
+    } else {
+      narrow_run<TB / 16, NT3>(Xs, br, [&](int row, int col, float v) {
+        if (row < rows_here && col < S) mean[row * S + col] = v + bias;
+      });
+    }
   } else {
     layer_tr2([] {});
     narrow_layer(Xs, Wp(MOBODY_DL_TR3), HID, a.L.layer[MOBODY_DL_TR3].Np, [&](int row, int col, float v) {
@@ -287,7 +294,8 @@ static int launch_dyn_fwd_t(const DynFwdArgs& a, hipStream_t st) {
 }
 template <int MT, int NPL>
 static int launch_dyn_fwd_nt(const DynFwdArgs& a, int nt3, hipStream_t st) {
-  return nt3 == 1 ? launch_dyn_fwd_t<MT, 1, NPL>(a, st) : nt3 == 2 ? launch_dyn_fwd_t<MT, 2, NPL>(a, st) : launch_dyn_fwd_t<MT, 0, NPL>(a, st);
+  return nt3 == 1 ? launch_dyn_fwd_t<MT, 1, NPL>(a, st) : nt3 == 2 ? launch_dyn_fwd_t<MT, 2, NPL>(a, st)
+       : nt3 == 3 ? launch_dyn_fwd_t<MT, 3, NPL>(a, st) : nt3 == 7 ? launch_dyn_fwd_t<MT, 7, NPL>(a, st) : launch_dyn_fwd_t<MT, 0, NPL>(a, st);
 }
 
 static int launch_dyn_fwd(const float* blob, const MobodyDynLayout& L, const float* obs, const float* act, long long B,
@@ -297,7 +305,7 @@ static int launch_dyn_fwd(const float* blob, const MobodyDynLayout& L, const flo
   // the waves (measured 102 vs 88 TFLOP/s at 50 000 rows); MOBODY_DYN_TILE_ROWS=32 selects the short tile.
   static const int forced = [] { const char* e = getenv("MOBODY_DYN_TILE_ROWS"); return e ? atoi(e) : 0; }();
   const int np = L.layer[MOBODY_DL_TR3].Np;
-  const int nt3 = np == 16 ? 1 : np == 32 ? 2 : 0;
+  const int nt3 = np == 16 ? 1 : np == 32 ? 2 : np == 48 ? 3 : np == 112 ? 7 : 0;      // walker/hopper/cheetah, pen, ant heads; else generic
   if (prec == 0) return forced == 32 ? launch_dyn_fwd_nt<1, 0>(a, nt3, st) : launch_dyn_fwd_nt<2, 0>(a, nt3, st);
   // split-precision modes: the planes of a 64-row tile are 34 / 68 / 101 KB for 1 / 2 / 3 terms -> the three-term mode
   // runs 32-row tiles (51 KB, three workgroups per CU)

@@ -328,6 +328,61 @@ __device__ __forceinline__ void narrow_run(float* Xs, const NarrowRegs<NT>& br, 
   }
 }
 
+// The same K-split layer for wider heads (Np = 16*NT up to 128: pen 48, ant 112), 32 rows per pass so the accumulators stay at
+// 8*NT registers: the four partial results of a pass meet in the LDS region of the rows it just consumed, through TWO
+// buffers (waves 2,3 store, waves 0,1 add their own onto them, then everyone sums the two) because four buffers of
+// 32 x 112 floats do not fit under a 32-row image.  f(row, col, value) once per output element; overwrites Xs.
+template <int MTN, int NT, class F>
+__device__ __forceinline__ void narrow_run_wide(float* Xs, const NarrowRegs<NT>& br, F&& f) {
+  static_assert(MTN % 2 == 0 && 2 * 32 * 16 * NT <= 32 * LDX, "32-row passes, two partial buffers inside the pass's rows");
+  constexpr int Np = 16 * NT, PB = 32 * Np;
+  const int lane = lane_id(), w = wave_id();
+  const int i = lane & 15, q = lane >> 4;
+#pragma unroll 1
+  for (int p = 0; p < MTN / 2; ++p) {
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][n][r] = 0.f;
+    const float* xa = Xs + (32 * p + i) * LDX + 64 * w + 16 * q;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      f32x4 av[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) av[m] = *reinterpret_cast<const f32x4*>(xa + 16 * m * LDX + 4 * s4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m][u], br.b[4 * s4 + u][n], acc[m][n], 0, 0, 0);
+    }
+    lds_barrier();                               // every wave has read this pass's 32 rows
+    float* P = Xs + 32 * p * LDX + (w & 1) * PB;
+    auto sweep = [&](bool add) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* d = P + (16 * m + 4 * q + r) * Np + 16 * n + i;
+            *d = add ? *d + acc[m][n][r] : acc[m][n][r];
+          }
+    };
+    if (w >= 2) sweep(false);
+    lds_barrier();
+    if (w < 2) sweep(true);
+    lds_barrier();
+    const float* S0 = Xs + 32 * p * LDX;
+    for (int e = threadIdx.x; e < PB; e += NTHREADS) f(32 * p + e / Np, e % Np, S0[e] + S0[PB + e]);
+  }
+}
+
 // --------------------------------------------------------------------------------------------
 // LDS tile fill: X[r][col0 + c] = src[(row0+r)*ld + c] for c < n (zero for rows >= rows).
 // --------------------------------------------------------------------------------------------
