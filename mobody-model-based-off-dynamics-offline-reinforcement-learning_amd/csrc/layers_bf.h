@@ -34,6 +34,7 @@ __device__ __forceinline__ void wide_layer_to_planes(float* Xs, __bf16* Ps, int 
   f32x16 acc[MT][2];
   wide_zero<MT>(acc);
   wide_gemm<MT>(Xs, W, Kp, acc, ring);
+  TR(6);
   between();
   lds_barrier();
   auto body = [&](auto guarded) {
@@ -48,6 +49,7 @@ __device__ __forceinline__ void wide_layer_to_planes(float* Xs, __bf16* Ps, int 
   };
   if (full) body(std::false_type{});
   else body(std::true_type{});
+  TR(7);
   if (mask != nullptr) relu_mask_words<MT>(acc, bias0, bias1, mask, mask_groups);
   lds_barrier();
 }

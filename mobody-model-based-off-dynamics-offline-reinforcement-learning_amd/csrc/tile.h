@@ -102,8 +102,7 @@ __device__ __forceinline__ void wide_ldb(const float* __restrict__ W, int Kp, in
 __device__ __forceinline__ void wide_prefetch(const float* __restrict__ W, int Kp, WideRing& ring) {
   const int nch = Kp >> 3;
 #pragma unroll
-  for (int j = 0; j < WIDE_RING - 1; ++j)
-    if (j < nch) wide_ldb(W, Kp, j, ring.r[j]);
+  for (int j = 0; j < WIDE_RING - 1; ++j) wide_ldb(W, Kp, min(j, nch - 1), ring.r[j]);   // unconditional (see wide_gemm)
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -131,19 +130,22 @@ __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const fl
       }
     __builtin_amdgcn_s_setprio(0);
   };
+  // A K known at compile time (the 256-wide layers) unrolls completely and drops the loads past the last chunk.  A runtime
+  // K (layer 1) keeps every load UNCONDITIONAL, from a clamped chunk index: with a load inside a branch the compiler's
+  // vmcnt bookkeeping merges the two paths and waits for the loads it has just issued (seen in the ISA of the K = 24
+  // layer: load, load, vmcnt(1), mfma -- one L2 round trip per chunk, 7 us for a layer with 0.6 us of MFMA work).
+  const bool known = __builtin_constant_p(Kp);
   for (int c0 = 0; c0 < nch; c0 += R) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const int c = c0 + j;
-      if (c < nch) {
-        if (c + R - 1 < nch) wide_ldb(W, Kp, c + R - 1, ring.r[(j + R - 1) % R]);
-        // Pin the issue order: without this fence hipcc sinks each prefetch load down to its first use (it trades
-        // the ring's registers for occupancy), which collapses the 4-chunk prefetch distance to ~1 chunk and puts
-        // an L2 round trip in front of every chunk's MFMAs (seen in the ISA: load ... vmcnt(1) ... mfma of it).
-        __builtin_amdgcn_sched_barrier(0);
-        mma(c, ring.r[j]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      if (!known || c + R - 1 < nch) wide_ldb(W, Kp, min(c + R - 1, nch - 1), ring.r[(j + R - 1) % R]);
+      // Pin the issue order: without this fence hipcc sinks each prefetch load down to its first use (it trades
+      // the ring's registers for occupancy), which collapses the 4-chunk prefetch distance to ~1 chunk and puts
+      // an L2 round trip in front of every chunk's MFMAs (seen in the ISA: load ... vmcnt(1) ... mfma of it).
+      __builtin_amdgcn_sched_barrier(0);
+      if (c < nch) mma(c, ring.r[j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -224,15 +226,19 @@ __device__ __forceinline__ void narrow_gemm(const float* __restrict__ Xs, const 
       }
     }
   };
+  // The loads are unconditional (clamped inside loadB): a load behind a branch makes the compiler wait for the loads it
+  // has just issued at the merge point (see wide_gemm).  Only the MFMAs of a chunk past the end are skipped.
   float b0[C][2][NT], b1[C][2][NT];
   loadB(0, b0);
   for (int p = 0; p < steps; p += 2 * C) {
-    if (p + C < steps) loadB(p + C, b1);
+    loadB(p + C, b1);
+    __builtin_amdgcn_sched_barrier(0);
     mma(p, b0);
-    if (p + C < steps) {
-      if (p + 2 * C < steps) loadB(p + 2 * C, b0);
-      mma(p + C, b1);
-    }
+    __builtin_amdgcn_sched_barrier(0);
+    loadB(p + 2 * C, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (p + C < steps) mma(p + C, b1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int n = 0; n < NT; ++n)

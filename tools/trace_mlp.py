@@ -60,6 +60,10 @@ def report(title, tt, names):
 
 if mode == "fwd":
     report("twin-Q forward", t, FWD)
+    if cfg["mfma"] != "f32":                      # slots 6, 7: layer-1 GEMM done / layer-1 epilogue (plane split + h1 save) done
+        us = (t - t[:, 0].min()) / 100.0
+        print(f"  layer 1 (split-precision tile): gemm done {us[:, 6].mean():.2f}, epilogue done {us[:, 7].mean():.2f}, "
+              f"barrier passed {us[:, 2].mean():.2f}")
 elif mode == "critic":
     report("critic backward", t, BWD)
 else:
