@@ -573,6 +573,15 @@ class MOBODY(object):
             writer.add_scalar("train/q_loss", q_loss, self.total_it)
             writer.add_scalar("train/policy_loss", pi_loss, self.total_it)
             writer.add_scalar("train/bc_loss", bc_loss, self.total_it)
+            # the reference's value scalars (:203-205, :332-338); read here after this step's updates, not between them
+            prec = self.precision
+            q12 = ops.mlp3_forward(self.q_funcs.blob, self.S + self.A, 1, 2, b[0], b[1], blob_T=self.q_funcs.blob_T, precision=prec)
+            pi = ops.mlp3_forward(self.policy.blob, self.S, self.A, 1, b[0], out_mode=1, max_action=cfg["max_action"],
+                                  blob_T=self.policy.blob_T, precision=prec)[0]
+            qpi = ops.mlp3_forward(self.q_funcs.blob, self.S + self.A, 1, 2, b[0], pi, blob_T=self.q_funcs.blob_T, precision=prec)
+            writer.add_scalar("train/q1", q12[0].mean(), self.total_it)
+            writer.add_scalar("train/q_behavior", torch.minimum(q12[0], q12[1]).mean(), self.total_it)
+            writer.add_scalar("train/q_policy", torch.minimum(qpi[0], qpi[1]).mean(), self.total_it)
             if wandbrun is not None:
                 wandbrun.log({"train/policy_loss": pi_loss, "train/q_loss": q_loss}, step=self.total_it)
 

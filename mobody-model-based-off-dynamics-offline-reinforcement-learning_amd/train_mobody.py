@@ -65,7 +65,30 @@ def build_parser():
     p.add_argument("--tar_rows", default=5000, type=int)
     p.add_argument("--log_every", default=1000, type=int)
     p.add_argument("--dynamics_max_epochs", default=None, type=int, help="cap on pre-training epochs (reference: until early stopping)")
+    p.add_argument("--scalars", default=1, type=int, help="1: write the writer.add_scalar stream to <outdir>/tb/scalars.csv")
     return p
+
+
+class ScalarLog:
+    """The `writer` the reference hands to policy.train / dynamics.train (a tensorboard SummaryWriter,
+    train_mobody.py:455-458): same add_scalar(tag, value, global_step) surface, rows appended to a CSV file (tensorboard is
+    not part of this image).  Values may be device tensors; they are read when the row is written."""
+
+    def __init__(self, path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        self.path = path
+        self.f = open(path, "w")
+        self.f.write("tag,step,value\n")
+
+    def add_scalar(self, tag, scalar_value, global_step=None, *_, **__):
+        v = float(scalar_value.item() if hasattr(scalar_value, "item") else scalar_value)
+        self.f.write(f"{tag},{-1 if global_step is None else int(global_step)},{v!r}\n")
+
+    def flush(self):
+        self.f.flush()
+
+    def close(self):
+        self.f.close()
 
 
 def domain_of(env):
@@ -201,16 +224,29 @@ def main(argv=None):
     outdir = f"{args.dir}/{args.policy}/{args.env}-srcdatatype-{args.srctype}-tardatatype-{args.tartype}-{args.shift_level}/r{args.seed}{args.out_dir_remark}"
     if args.save_model:
         os.makedirs(f"{outdir}/models", exist_ok=True)
+    writer = ScalarLog(f"{outdir}/tb/scalars.csv") if args.scalars else None          # train_mobody.py:455-458
     start = time.time()
     for t in range(int(config["max_step"])):
-        policy.train(src_rb, tar_rb, config["batch_size"], None, None)
+        policy.train(src_rb, tar_rb, config["batch_size"], writer, None)
         if (t + 1) % args.log_every == 0:
             q, pi, bc = policy.losses()
             dt = time.time() - start
             print(f"step {t + 1}: q_loss {q:.4f} pi_loss {pi:.4f} bc_loss {bc:.4f}  {args.log_every / dt:.1f} grad-steps/s")
             start = time.time()
-        if (t + 1) % config["eval_freq"] == 0 and args.save_model:
-            policy.save(f"{outdir}/models/model")
+        if (t + 1) % config["eval_freq"] == 0:
+            # The reference's evaluation block (train_mobody.py:928-975) rolls the policy out in the simulators; of it, what
+            # does not need a simulator is kept on the same cadence: the transition model's error on TARGET transitions
+            # (eval_policy_batch's obs-RMSE / reward-MSE, :100-133, here on a target-buffer batch) and the model checkpoint.
+            if writer is not None:
+                s_, a_, s2_, r_, _ = tar_rb.sample(min(1000, tar_rb.size))
+                err = dynamics.model_error(s_, a_, s2_, r_)
+                writer.add_scalar("test/model error next_obs", err["obs_mse"], global_step=t + 1)
+                writer.add_scalar("test/model error reward", err["reward_mse"], global_step=t + 1)
+                writer.flush()
+            if args.save_model:
+                policy.save(f"{outdir}/models/model")
+    if writer is not None:
+        writer.close()
     torch.cuda.synchronize()
     return policy
 

@@ -56,6 +56,11 @@ def test_cli_runs_end_to_end_on_synthetic_buffers(tmp_path, capsys):
     assert sorted(os.listdir(models)) == ["model_actor", "model_actor_optimizer", "model_critic", "model_critic_optimizer"]
     sd = torch.load(os.path.join(models, "model_actor"), weights_only=True)
     assert sorted(sd) == sorted(f"network.network.{i}.{w}" for i in (0, 2, 4) for w in ("weight", "bias"))
+    # the writer stream (SummaryWriter surface): the model-error pair on the eval cadence (step 10), finite values
+    rows = [l.strip().split(",") for l in open(os.path.join(os.path.dirname(models), "tb", "scalars.csv"))][1:]
+    tags = {(r[0], int(r[1])) for r in rows}
+    assert ("test/model error next_obs", 10) in tags and ("test/model error reward", 10) in tags
+    assert all(float(r[2]) == float(r[2]) for r in rows)
 
 
 @pytest.mark.gpu

@@ -583,3 +583,37 @@ def test_reference_written_checkpoint_loads_and_continues(dev):
     for nm, net in (("q", pol.q_funcs), ("actor", pol.policy)):
         for k, v in net.state_dict().items():
             params_close(gu.sub(v.cpu().numpy()), g[f"s3_{nm}_p::{k}"], cfg["critic_lr"])
+
+
+def test_writer_scalars_on_the_reference_cadence(dev, tmp_path):
+    """train(..., writer): the add_scalar stream of mobody.py:203-205,272-274,332-338 (every 5000th step; graph replay gives
+    way to the eager step on those), through the CLI's CSV sink.  The logged losses equal the step's loss words and the
+    value scalars equal a direct forward of the post-update nets."""
+    from mobody_amd import synthetic, ops
+    from mobody_amd.algo import utils
+    from mobody_amd.algo.call_algo import call_algo
+    from mobody_amd.train_mobody import ScalarLog
+    S, A, task, bs = 17, 6, "walker2d-medium-v2", 64
+    torch.manual_seed(3)
+    cfg = gu.policy_cfg(S, A, rng="device", seed=7, graph=1, src_rollout_length=0, trg_rollout_length=0,
+                        use_src_sa_to_get_target_next_state=0)
+    pol = call_algo("mobody", cfg, 3, dev)
+    rows = gu.gi.batch(9, 300, S, A)
+    pol.fake_replay_buffer.add_batch(dict(obss=rows[0], actions=rows[1], next_obss=rows[2], rewards=rows[3], terminals=1.0 - rows[4]))
+    src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=4000, rng="device", seed=1), 4000, task, 0)
+    tar = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=500, rng="device", seed=2), 500, task, 1)
+    w = ScalarLog(str(tmp_path / "tb" / "scalars.csv"))
+    for _ in range(3):
+        pol.train(src, tar, bs, w, None)
+    pol.total_it = 4999                                           # next step is a logging step
+    pol.train(src, tar, bs, w, None)
+    w.close()
+    got = {r[0]: (int(r[1]), float(r[2])) for r in (l.strip().split(",") for l in list(open(w.path))[1:])}
+    assert set(got) == {"train/q_loss", "train/policy_loss", "train/bc_loss", "train/q1", "train/q_behavior", "train/q_policy"}
+    assert all(step == 5000 for step, _ in got.values())
+    q, pi, bc = pol.losses()
+    assert (got["train/q_loss"][1], got["train/policy_loss"][1], got["train/bc_loss"][1]) == (q, pi, bc)
+    b = pol._batch
+    q12 = ops.mlp3_forward(pol.q_funcs.blob, S + A, 1, 2, b[0], b[1])
+    close(torch.tensor(got["train/q1"][1]), q12[0].mean().cpu(), rtol=1e-5, atol=1e-6)
+    close(torch.tensor(got["train/q_behavior"][1]), torch.minimum(q12[0], q12[1]).mean().cpu(), rtol=1e-5, atol=1e-6)
