@@ -12,7 +12,7 @@ def test_cli_flags_match_the_reference_table():
     from mobody_amd import train_mobody as tm
     want = {f["flag"]: f for f in json.load(open(os.path.join(ROOT, "tests", "golden", "g10_cli_flags.json")))}
     got = {a.option_strings[0]: a for a in tm.build_parser()._actions if a.option_strings and a.option_strings[0] != "-h"}
-    extra = {"--synthetic", "--rng", "--src_rows", "--tar_rows", "--log_every", "--dynamics_max_epochs"}            # additions of this build
+    extra = {"--synthetic", "--rng", "--src_rows", "--tar_rows", "--log_every", "--dynamics_max_epochs", "--scalars"}   # additions of this build
     assert set(got) - extra == set(want)
     for flag, f in want.items():
         a = got[flag]
