@@ -50,14 +50,15 @@ def dataset_path(tar_env_name, shift_scale, quality="random", root=None):
     return os.path.join(root, domain, tail)
 
 
-def call_tar_dataset(tar_env_name, shift_scale, quality="random", root=None):
+def transitions_from_hdf5(path):
+    """Every dataset of an ODRL HDF5 file (call_dataset.py:53-66, the get_keys walk) through transitions_from_arrays."""
     try:
         import h5py
     except ImportError as exc:
-        raise ImportError("call_tar_dataset reads ODRL HDF5 files and needs h5py; feed transitions_from_arrays() with the "
-                          "file's arrays instead") from exc
+        raise ImportError("ODRL HDF5 files need h5py; feed transitions_from_arrays() with the file's arrays (e.g. from an "
+                          ".npz copy) instead") from exc
     data = {}
-    with h5py.File(dataset_path(tar_env_name, shift_scale, quality, root), "r") as f:
+    with h5py.File(path, "r") as f:
         def visit(name, item):
             if isinstance(item, h5py.Dataset):
                 try:
@@ -66,3 +67,7 @@ def call_tar_dataset(tar_env_name, shift_scale, quality="random", root=None):
                     data[name] = item[()]
         f.visititems(visit)
     return transitions_from_arrays(data)
+
+
+def call_tar_dataset(tar_env_name, shift_scale, quality="random", root=None):
+    return transitions_from_hdf5(dataset_path(tar_env_name, shift_scale, quality, root))

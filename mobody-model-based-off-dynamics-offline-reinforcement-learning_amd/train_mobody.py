@@ -7,8 +7,10 @@ dynamics -> attach -> `policy.train(...)` loop (:927-928).
 
 Simulators (gym / mujoco-py / d4rl) and datasets are not part of this build: `--synthetic 1` (the
 default when gym/d4rl are not importable) fills the replay buffers with synthetic MuJoCo-shaped
-transitions and random-initialised networks and skips simulator evaluation; with
-`--synthetic 0` the script needs d4rl/gym exactly like the reference.  `--train_dynamics 1` pre-trains the
+transitions and random-initialised networks and skips simulator evaluation; `--synthetic 0` trains on real
+offline datasets without the simulators: `--src_data` (an .npz in d4rl.qlearning_dataset's layout) and `--tar_data` (the
+ODRL target file: .npz of its raw arrays, or the .hdf5 itself when h5py is importable; default: the reference's
+`dataset/<domain>/<env>_<shift>_<quality>.hdf5` path), ingested exactly as train_mobody.py:548-557 does.  `--train_dynamics 1` pre-trains the
 ensemble dynamics on the buffers (MOBODYEnsembleDynamics.train) and saves it under `--dynamics_path` in the
 reference's directory scheme; an existing `dynamics.pth` there is loaded instead when `--train_dynamics 0`.
 """
@@ -66,6 +68,9 @@ def build_parser():
     p.add_argument("--log_every", default=1000, type=int)
     p.add_argument("--dynamics_max_epochs", default=None, type=int, help="cap on pre-training epochs (reference: until early stopping)")
     p.add_argument("--scalars", default=1, type=int, help="1: write the writer.add_scalar stream to <outdir>/tb/scalars.csv")
+    p.add_argument("--src_data", default=None, help="--synthetic 0: source transitions (.npz in d4rl.qlearning_dataset layout)")
+    p.add_argument("--tar_data", default=None, help="--synthetic 0: target ODRL dataset (.npz of its raw arrays, or the .hdf5 itself "
+                                                     "when h5py is importable); default: the reference's dataset/<domain>/... path")
     return p
 
 
@@ -89,6 +94,26 @@ class ScalarLog:
 
     def close(self):
         self.f.close()
+
+
+def load_datasets(args):
+    """The two offline datasets of the real-data mode without simulators: the source transitions the reference takes from
+    d4rl.qlearning_dataset (train_mobody.py:548-552) come from an .npz file with the same keys, the target transitions from
+    the ODRL file through dataset/call_dataset.py's transformation (:553-557)."""
+    from mobody_amd.dataset import call_dataset
+    if args.src_data is None:
+        raise NotImplementedError("--synthetic 0 without simulators needs --src_data FILE.npz (observations, actions, "
+                                  "next_observations, rewards, terminals: d4rl.qlearning_dataset's keys); d4rl itself is not in this image")
+    with np.load(args.src_data) as z:
+        src = {k: z[k] for k in ("observations", "actions", "next_observations", "rewards", "terminals")}
+    if args.tar_data is not None and args.tar_data.endswith(".npz"):
+        with np.load(args.tar_data) as z:
+            tar = call_dataset.transitions_from_arrays({k: z[k] for k in z.files})
+    elif args.tar_data is not None:
+        tar = call_dataset.transitions_from_hdf5(args.tar_data)
+    else:
+        tar = call_dataset.call_tar_dataset(args.env, args.shift_level, args.tartype)
+    return src, tar
 
 
 def domain_of(env):
@@ -175,9 +200,13 @@ def main(argv=None):
             synthetic_mode = 0
         except Exception:
             synthetic_mode = 1
-    if not synthetic_mode:
-        raise NotImplementedError("real-dataset mode needs gym/d4rl/mujoco-py, which this image lacks; use --synthetic 1")
     state_dim, action_dim, task = synthetic.env_shape(args.env)
+    src_ds = tar_ds = None
+    if not synthetic_mode:
+        src_ds, tar_ds = load_datasets(args)
+        if src_ds["observations"].shape[1] != state_dim or src_ds["actions"].shape[1] != action_dim:
+            raise ValueError(f"--src_data has shapes {src_ds['observations'].shape[1]}/{src_ds['actions'].shape[1]}, "
+                             f"env {args.env} expects {state_dim}/{action_dim}")
     max_action = 1.0
     torch.manual_seed(args.seed); np.random.seed(args.seed); random.seed(args.seed)
     torch.cuda.manual_seed_all(args.seed)
@@ -190,8 +219,13 @@ def main(argv=None):
     policy = call_algo(args.policy, config, args.mode, device, terminal_fn=terminal_fn)
     src_rb = utils.ReplayBuffer(state_dim, action_dim, device, rng=args.rng, seed=args.seed + 1)
     tar_rb = utils.ReplayBuffer(state_dim, action_dim, device, rng=args.rng, seed=args.seed + 2)
-    synthetic.fill_buffer(src_rb, args.src_rows, task, args.seed)
-    synthetic.fill_buffer(tar_rb, args.tar_rows, task, args.seed + 100)
+    if synthetic_mode:
+        synthetic.fill_buffer(src_rb, args.src_rows, task, args.seed)
+        synthetic.fill_buffer(tar_rb, args.tar_rows, task, args.seed + 100)
+    else:                                             # train_mobody.py:548-557: both buffers adopt their datasets
+        src_rb.convert_D4RL(src_ds)
+        tar_rb.convert_D4RL(tar_ds)
+        print(f"datasets: {src_rb.size} source / {tar_rb.size} target transitions")
 
     model = MOBODYModule(obs_dim=state_dim, action_dim=action_dim, hidden_dims=256, num_ensemble=7, num_elites=5,
                          weight_decays=[2.5e-5, 5e-5, 7.5e-5, 7.5e-5, 1e-4], device=device,

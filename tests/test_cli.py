@@ -12,7 +12,7 @@ def test_cli_flags_match_the_reference_table():
     from mobody_amd import train_mobody as tm
     want = {f["flag"]: f for f in json.load(open(os.path.join(ROOT, "tests", "golden", "g10_cli_flags.json")))}
     got = {a.option_strings[0]: a for a in tm.build_parser()._actions if a.option_strings and a.option_strings[0] != "-h"}
-    extra = {"--synthetic", "--rng", "--src_rows", "--tar_rows", "--log_every", "--dynamics_max_epochs", "--scalars"}   # additions of this build
+    extra = {"--synthetic", "--rng", "--src_rows", "--tar_rows", "--log_every", "--dynamics_max_epochs", "--scalars", "--src_data", "--tar_data"}   # additions of this build
     assert set(got) - extra == set(want)
     for flag, f in want.items():
         a = got[flag]
@@ -113,3 +113,32 @@ def test_merged_config_matches_the_reference_mapping():
     for name in ("ant", "halfcheetah", "hopper"):             # the built-in yaml copy covers all four shipped files
         yy = g["yaml"][f"mujoco/mobody/{name}.yaml"]
         assert {k: v for k, v in yy.items() if k != "eval_freq"} == {k: v for k, v in y.items() if k != "eval_freq"}
+
+
+@pytest.mark.gpu
+def test_cli_real_dataset_mode_without_simulators(tmp_path, capsys):
+    """--synthetic 0: source transitions from an .npz in d4rl.qlearning_dataset's layout, target transitions from the raw
+    arrays of an ODRL file through dataset/call_dataset.py's shift-by-one transformation (train_mobody.py:548-557)."""
+    import numpy as np
+    from mobody_amd import train_mobody as tm
+    rng = np.random.default_rng(5)
+    S, A, n, m = 17, 6, 3000, 801
+    mu = np.zeros(S, np.float32); mu[0] = 1.25
+    obs = (mu + 0.1 * rng.standard_normal((n, S))).astype(np.float32)
+    np.savez(tmp_path / "src.npz", observations=obs, actions=rng.uniform(-1, 1, (n, A)).astype(np.float32),
+             next_observations=(obs + 0.01 * rng.standard_normal((n, S))).astype(np.float32),
+             rewards=rng.standard_normal(n).astype(np.float32), terminals=np.zeros(n, bool))
+    tobs = (mu + 0.1 * rng.standard_normal((m, S))).astype(np.float32)
+    np.savez(tmp_path / "tar.npz", observations=tobs, actions=rng.uniform(-1, 1, (m, A)).astype(np.float32),
+             rewards=rng.standard_normal((m, 1)).astype(np.float32), terminals=np.zeros(m, bool), timeouts=np.zeros(m, bool))
+    pol = tm.main(["--policy", "MOBODY", "--env", "walker2d-friction", "--shift_level", "2.0", "--mode", "3", "--seed", "2",
+                   "--synthetic", "0", "--src_data", str(tmp_path / "src.npz"), "--tar_data", str(tmp_path / "tar.npz"),
+                   "--penalty_type", "none", "--src_rollout_batch_size", "500", "--trg_rollout_batch_size", "200",
+                   "--max_step", "6", "--eval_freq", "5",
+                   "--params", '{"batch_size": 64, "max_step": 6, "eval_freq": 5}', "--log_every", "3", "--dir", str(tmp_path)])
+    out = capsys.readouterr().out
+    assert "datasets: 3000 source / 800 target transitions" in out        # N-1 target rows (shift by one)
+    assert pol.total_it == 6 and all(v == v for v in pol.losses())
+    with pytest.raises(ValueError):
+        tm.main(["--policy", "MOBODY", "--env", "ant-friction", "--mode", "3", "--synthetic", "0",
+                 "--src_data", str(tmp_path / "src.npz"), "--tar_data", str(tmp_path / "tar.npz")])
