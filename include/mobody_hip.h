@@ -209,11 +209,13 @@ int mobody_gather_batch(const MobodyBufferView* bufs, const int32_t* const* idx,
  * mode): index i of source k = philox(seeds[k], stream 3, call)[i] * size >> 32 with
  * call = (counter ? counter[0] : 0) + call_offsets[k] and size read from the DEVICE word sizes[k][0]
  * (`seeds`, `call_offsets`, `counts` and the `sizes` pointer array are host arrays).  Identical draws to
- * mobody_rng_index / mobody_sample_indices for the same (seed, call). */
+ * mobody_rng_index / mobody_sample_indices for the same (seed, call).  `bump`: host array of nbump <= 4 device int64
+ * words (none of them `counter`) that one thread of the launch increments by one (a captured step advances its Adam
+ * step counts here); nbump = 0: none. */
 int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64_t* counts, int nbuf, int S, int A,
                             const uint32_t* seeds, const int64_t* call_offsets, const int64_t* counter,
                             const int64_t* const* sizes, float* state, float* action, float* next_state,
-                            float* reward, float* not_done, void* stream);
+                            float* reward, float* not_done, int64_t* const* bump, int nbump, void* stream);
 
 /* Append the rows with keep[i] != 0 (NULL = all), in order, to the ring `ring` of `cap` rows (written through the
  * view's pointers) at *ptr_size (device int64[2] = {ptr, size}), reproducing add_batch's single-wrap arithmetic
@@ -267,8 +269,10 @@ int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper* h, const f
                          float* q_blob, float* q_blob_T, float* qtarg_blob, float* qtarg_blob_T, const float* state,
                          const float* action, const float* next_state, const float* reward, const float* not_done,
                          const float* q_next, float* m, float* v, int64_t t, const int64_t* t_dev, float lr,
-                         float* loss_out, float* workspace, int policy_forward, void* stream);
-/* qtarg_blob_T (nullable): the target net's T blob; when given, the W2 planes of the target follow the Polyak update. */
+                         float* loss_out, float* workspace, int policy_forward, int64_t* bump, void* stream);
+/* qtarg_blob_T (nullable): the target net's T blob; when given, the W2 planes of the target follow the Polyak update.
+ * bump (nullable, != t_dev): a device int64 word the optimizer launch increments by one -- a captured step advances the
+ * RNG call id it has already consumed here instead of in a launch of its own. */
 
 /* Actor phase, part 1: forwards + the two batch statistics stats[0]=sum|min Q(s,pi(s))|,
  * stats[1]=sum|min Q(s_t,a_t)| over LOCAL rows (all-reduce them across ranks before part 2). */

@@ -87,7 +87,8 @@ PROTOTYPES = {
     "mobody_gather_batch": (C.c_int, [C.POINTER(MobodyBufferView), C.POINTER(vp), C.POINTER(i64), C.c_int, C.c_int,
                                       C.c_int, vp, vp, vp, vp, vp, vp]),
     "mobody_gather_batch_rng": (C.c_int, [C.POINTER(MobodyBufferView), C.POINTER(i64), C.c_int, C.c_int, C.c_int,
-                                          C.POINTER(u32), C.POINTER(i64), vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp]),
+                                          C.POINTER(u32), C.POINTER(i64), vp, C.POINTER(vp), vp, vp, vp, vp, vp, C.POINTER(vp), C.c_int,
+                                          vp]),
     "mobody_ring_append": (C.c_int, [C.POINTER(MobodyBufferView), i64, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, i64, vp,
                                      vp]),
     "mobody_ring_pitch": (i64, [C.c_int, C.c_int]),
@@ -95,7 +96,7 @@ PROTOTYPES = {
     "mobody_critic_step": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                      vp, vp, vp, vp, vp, vp, C.c_int, vp]),
     "mobody_critic_update": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                                       vp, vp, vp, vp, vp, i64, vp, f32, vp, vp, C.c_int, vp]),
+                                       vp, vp, vp, vp, vp, i64, vp, f32, vp, vp, C.c_int, vp, vp]),
     "mobody_actor_update": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, vp, i64, vp, f32, vp, vp, vp]),
     "mobody_value_loss_grad": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp]),

@@ -448,10 +448,11 @@ class MOBODY(object):
             self.actor_stats(b, N, Nt, Ng, Ntg)
 
         def fused_step():
-            ops.counter_add(c)
-            ops.gather_batch_rng([rb._fields() for rb in bufs], cnts, seeds, [0] * len(bufs), c[0:1],
-                                 [rb.ptr_size[1:2] for rb in bufs], S, A, b)
-            self.critic_update(b, N, Nt, t_dev=c[1:2])
+            # no launch of its own for the three counters: the gather draws with call id c[0] + 1 and advances the two Adam
+            # step counts (it does not read them), the critic's optimizer launch advances c[0] (the gather is done with it)
+            ops.gather_batch_rng([rb._fields() for rb in bufs], cnts, seeds, [1] * len(bufs), c[0:1],
+                                 [rb.ptr_size[1:2] for rb in bufs], S, A, b, bump=(c[1:2], c[2:3]))
+            self.critic_update(b, N, Nt, t_dev=c[1:2], bump=c[0:1])
             self.actor_stats(b, N, Nt, N, Nt)
             self.actor_update(b, N, Nt, t_dev=c[2:3])
 
@@ -658,7 +659,7 @@ class MOBODY(object):
         between); not in the advantage variant, whose critic call has no target-Q launch."""
         return not self.config["advantage"]
 
-    def critic_update(self, b, N, Nt, t_dev=None):
+    def critic_update(self, b, N, Nt, t_dev=None, bump=None):
         """critic_grad + critic_apply in the fused single-GPU form (same arithmetic, no gradient blob)."""
         dims, hyp = self._dims(N, Nt, N, Nt)
         q_next = None
@@ -670,7 +671,7 @@ class MOBODY(object):
         ops.critic_update(dims, hyp, self.policy.blob, self.q_funcs.blob, self.q_funcs.blob_T, self.target_q_funcs.blob, b,
                           o.m, o.v, o.t, o.lr, self._loss[0:1], self._ws, q_next=q_next, t_dev=t_dev,
                           policy_forward=self._policy_rides_along(), actor_blob_T=self.policy.blob_T,
-                          qtarg_blob_T=self.target_q_funcs.blob_T)
+                          qtarg_blob_T=self.target_q_funcs.blob_T, bump=bump)
 
     def actor_update(self, b, N, Nt, t_dev=None):
         dims, hyp = self._dims(N, Nt, N, Nt)

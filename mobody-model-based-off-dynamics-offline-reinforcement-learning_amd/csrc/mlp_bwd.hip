@@ -645,6 +645,7 @@ __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
   adam_block_consts(a.adam, adam_sm);
   const long long nW = a.L.total_floats;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid == 0 && a.adam.bump != nullptr) a.adam.bump[0] += 1;      // graph replay: advance a counter no block of this launch reads
   if (gid < nW) {
     const long long j = gid;
     const long long o = j % a.L.member_floats;

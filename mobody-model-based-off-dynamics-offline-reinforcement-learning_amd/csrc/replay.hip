@@ -35,6 +35,8 @@ struct GatherArgs {
   long long call_offset[3];
   const long long* counter;
   const long long* size[3];
+  long long* bump[4];       // device words incremented by one thread (never `counter`): graph replay advances its step counts here
+  int nbump;
 };
 
 // field block f of `rows` staged rows -> contiguous output rows (all 256 threads, consecutive addresses)
@@ -53,6 +55,8 @@ __device__ __forceinline__ void stage_to_batch(const float* stage, int WS, int o
 __global__ __launch_bounds__(256) void k_gather(GatherArgs a) {
   extern __shared__ __attribute__((aligned(16))) float stage[];     // [16][WS]
   const int lane = threadIdx.x & 15, g = threadIdx.x >> 4;
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int k = 0; k < a.nbump; ++k) a.bump[k][0] += 1;
   const long long row0 = (long long)blockIdx.x * ROWS_WG;
   const long long row = row0 + g;
   const long long N = a.start[a.nbuf];
@@ -340,8 +344,9 @@ extern "C" int mobody_ring_append(const MobodyBufferView* ring, int64_t cap, int
 extern "C" int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64_t* counts, int nbuf, int S, int A,
                                        const uint32_t* seeds, const int64_t* call_offsets, const int64_t* counter,
                                        const int64_t* const* sizes, float* state, float* action, float* next_state,
-                                       float* reward, float* not_done, void* stream) {
+                                       float* reward, float* not_done, int64_t* const* bump, int nbump, void* stream) {
   MB_REQUIRE(bufs && counts && seeds && call_offsets && sizes && nbuf >= 1 && nbuf <= 3, "mobody_gather_batch_rng: need 1..3 source buffers");
+  MB_REQUIRE(nbump >= 0 && nbump <= 4 && (nbump == 0 || bump), "mobody_gather_batch_rng: at most 4 words to advance");
   GatherArgs a{};
   long long N;
   int rc = gather_common("mobody_gather_batch_rng", a, bufs, counts, nbuf, S, A, state, action, next_state, reward, not_done, N);
@@ -351,5 +356,10 @@ extern "C" int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64
     a.idx[k] = nullptr; a.seed[k] = seeds[k]; a.call_offset[k] = call_offsets[k]; a.size[k] = (const long long*)sizes[k];
   }
   a.counter = (const long long*)counter;
+  for (int k = 0; k < nbump; ++k) {
+    MB_REQUIRE(bump[k] && bump[k] != counter, "mobody_gather_batch_rng: bump word %d is null or the call counter itself", k);
+    a.bump[k] = (long long*)bump[k];
+  }
+  a.nbump = nbump;
   return launch_gather(a, N, as_stream(stream));
 }

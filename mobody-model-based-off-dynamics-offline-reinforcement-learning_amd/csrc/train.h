@@ -132,6 +132,7 @@ struct AdamTarget {
   const long long* t_dev;                   // device step count (graph replay) or null
   float lr;
   int on;                                   // k_grad_reduce only: 0 = just write the gradient
+  long long* bump;                          // k_grad_reduce only: device word incremented by one thread (not t_dev), or null
 };
 
 // Bias corrections of a device-side step count (graph replay), formed ONCE per workgroup in double: thread 0 computes,

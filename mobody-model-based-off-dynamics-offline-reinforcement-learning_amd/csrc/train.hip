@@ -327,11 +327,13 @@ extern "C" int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper*
                                     float* qtarg_blob_T, const float* state, const float* action, const float* next_state,
                                     const float* reward, const float* not_done, const float* q_next, float* m, float* v,
                                     int64_t t, const int64_t* t_dev, float lr, float* loss_out, float* workspace,
-                                    int policy_forward, void* stream) {
+                                    int policy_forward, int64_t* bump, void* stream) {
   MB_REQUIRE(h && q_blob && q_blob_T && qtarg_blob && m && v, "mobody_critic_update: null pointer");
   MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_critic_update: step t must be >= 1");
+  MB_REQUIRE(bump == nullptr || bump != t_dev, "mobody_critic_update: bump must not be the step word the launch reads");
   AdamTarget at = adam_target(q_blob, q_blob_T, m, v, qtarg_blob, t, t_dev, lr, h->tau, 1.f);
   at.target_T = qtarg_blob_T;
+  at.bump = (long long*)bump;
   return critic_impl(d, h, actor_blob, actor_blob_T, q_blob, q_blob_T, qtarg_blob, qtarg_blob_T, state, action, next_state, reward,
                      not_done, q_next, nullptr, at, loss_out, workspace, policy_forward, stream);
 }

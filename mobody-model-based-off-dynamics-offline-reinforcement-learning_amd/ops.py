@@ -165,13 +165,14 @@ def actor_backward(dims, hyp, actor_blob, actor_blob_T, q_blob, q_blob_T, state,
 
 
 def critic_update(dims, hyp, actor_blob, q_blob, q_blob_T, qtarg_blob, batch, m, v, t, lr, loss_out, ws, q_next=None,
-                  t_dev=None, policy_forward=False, actor_blob_T=None, qtarg_blob_T=None):
-    """critic_step + Adam + Polyak in the fused single-GPU form (t: host step count, or t_dev: device int64[1])."""
+                  t_dev=None, policy_forward=False, actor_blob_T=None, qtarg_blob_T=None, bump=None):
+    """critic_step + Adam + Polyak in the fused single-GPU form (t: host step count, or t_dev: device int64[1]);
+    bump: device int64[1] word (not t_dev) the optimizer launch increments by one."""
     s, a, s2, r, nd = batch
     check(load().mobody_critic_update(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(actor_blob_T), ptr(q_blob), ptr(q_blob_T),
                                       ptr(qtarg_blob), ptr(qtarg_blob_T), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(q_next), ptr(m),
                                       ptr(v), int(t), ptr(t_dev), float(lr), ptr(loss_out), ptr(ws),
-                                      int(bool(policy_forward)), cur_stream()),
+                                      int(bool(policy_forward)), ptr(bump), cur_stream()),
           "mobody_critic_update")
 
 
@@ -311,16 +312,18 @@ def adam_polyak_dev(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, 
                                         cur_stream()), "mobody_adam_polyak_dev")
 
 
-def gather_batch_rng(buffers, counts, seeds, call_offsets, counter, sizes, S, A, out):
-    """Gather with device-drawn indices: buffers = list of 5-tuples, sizes = list of device int64[1] views,
-    counter = device int64[1] or None.  `out` = (state, action, next_state, reward, not_done) destination tensors."""
+def gather_batch_rng(buffers, counts, seeds, call_offsets, counter, sizes, S, A, out, bump=()):
+    """Gather with device-drawn indices: buffers = list of RingView / 5-tuples, sizes = list of device int64[1] views,
+    counter = device int64[1] or None.  `out` = (state, action, next_state, reward, not_done) destination tensors.
+    bump: up to four device int64[1] words (not `counter`) the launch increments by one."""
     n = len(buffers)
     views = (_lib.MobodyBufferView * n)(*[buffer_view(b) for b in buffers])
     cnt = (C.c_int64 * n)(*[int(c) for c in counts])
     sd = (C.c_uint32 * n)(*[int(s) & 0xFFFFFFFF for s in seeds])
     off = (C.c_int64 * n)(*[int(o) for o in call_offsets])
     sz = (C.c_void_p * n)(*[ptr(s) for s in sizes])
-    check(load().mobody_gather_batch_rng(views, cnt, n, S, A, sd, off, ptr(counter), sz, *[ptr(t) for t in out],
+    bp = (C.c_void_p * max(1, len(bump)))(*[ptr(t) for t in bump])
+    check(load().mobody_gather_batch_rng(views, cnt, n, S, A, sd, off, ptr(counter), sz, *[ptr(t) for t in out], bp, len(bump),
                                          cur_stream()), "mobody_gather_batch_rng")
     return out
 
