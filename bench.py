@@ -435,8 +435,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
             "config": {"workload": f"{args.config}: {c['label']} (S={S} A={A}, ensemble 7, rollout_len {c['H']}, N={N} rows per "
                                    f"train() step: src|tar|fake = {bs}|{bs}|{bs // 2}), "
-                                   + ("exact fp32 MFMA" if args.mfma == "f32" else f"256x256 forward layers on the {args.mfma} split-precision MFMA core, "
-                                      "everything else exact fp32 MFMA"),
+                                   + ("exact fp32 MFMA" if args.mfma == "f32" else f"256x256 GEMMs (forward, backward, weight gradient) on the {args.mfma} split-precision MFMA "
+                                      "core, everything else exact fp32 MFMA"),
                        "name": args.config, "rows_per_step_per_gpu": N, "parallelism": f"dp{world}", "hip_graph": graph_on},
             "grad_steps_per_sec": args.steps / dt,
             "grad_steps_per_sec_refresh_excluded": args.steps / dt_steps,
