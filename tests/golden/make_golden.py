@@ -746,7 +746,48 @@ def g16():
     save("g16_ckpt_step3", **out)
 
 
+# --------------------------------------------------------------------------- G17
+class RotatingRB(FixedRB):
+    """Preset rows, a different window of them per call: sample k returns rows [(k * 13) % (size - n) ...)."""
+
+    def sample(self, n):
+        k = len(self.calls)
+        self.calls.append(n)
+        o = (k * 13) % (self.size - n + 1)
+        return tuple(r[o:o + n].clone() for r in self.rows)
+
+
+def g17():
+    """A 30-step train() trajectory (no refresh inside): per-step losses and the final parameters.  Pins that the mirror
+    TRACKS the reference over many optimizer steps (Adam moments, bias corrections, Polyak target), not only steps 1-2."""
+    S, A, bs, steps = 17, 6, 32, 30
+    cfg = policy_cfg(S, A)
+    pol, pa, pq, pv = make_policy(cfg, 411)
+    src = RotatingRB(gi.batch(511, 96, S, A)); tar = RotatingRB(gi.batch(512, 96, S, A)); fake = RotatingRB(gi.batch(513, 96, S, A))
+    pol.fake_replay_buffer = fake
+    rec = dict(q_loss=[], pi_loss=[], bc_loss=[])
+    for nm, key in (("update_q_functions", "q_loss"), ("update_policy", "pi_loss"), ("bc_loss", "bc_loss")):
+        def mk(orig, key):
+            def f(*a, **k):
+                o = orig(*a, **k); rec[key].append(float(o.detach())); return o
+            return f
+        setattr(pol, nm, mk(getattr(pol, nm), key))
+    pol.total_it = 1
+    dummy = types.SimpleNamespace(log=lambda *a, **k: None)
+    for _ in range(steps):
+        pol.train(src, tar, bs, None, dummy)
+    out = dict(S=S, A=A, bs=bs, steps=steps, seed=411, wsum_actor=gi.checksum(pa), wsum_q=gi.checksum(pq),
+               q_loss=np.array(rec["q_loss"]), pi_loss=np.array(rec["pi_loss"]), bc_loss=np.array(rec["bc_loss"]),
+               calls_src=np.array(src.calls), calls_tar=np.array(tar.calls), calls_fake=np.array(fake.calls))
+    for nm, mod in (("q", pol.q_funcs), ("actor", pol.policy), ("qt", pol.target_q_funcs)):
+        for k, v in mod.state_dict().items():
+            out[f"final_{nm}_p::{k}"] = sub(v.numpy())
+    print("trajectory q_loss", rec["q_loss"][0], "->", rec["q_loss"][-1], "pi_loss", rec["pi_loss"][0], "->", rec["pi_loss"][-1],
+          "calls", src.calls[:3], tar.calls[:3], fake.calls[:3])
+    save("g17_train_trajectory", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g16"]
+    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g16", "g17"]
     for w in which:
         globals()[w]()

@@ -67,3 +67,12 @@ def g7_batch(cfg, bs, S, A, src_reward_override=None):
         parts.append([x[:nf].copy() for x in fake])
     batch = tuple(np.concatenate([p[i] for p in parts], 0) for i in range(5))
     return batch, ns + nt
+
+
+def g17_batch(k, cfg, bs, S, A):
+    """Mixed batch of trajectory step k (0-based) as make_golden.py::RotatingRB serves it: window offset (k * 13) % (96 - n + 1)."""
+    src = gi.batch(511, 96, S, A); tar = gi.batch(512, 96, S, A); fake = gi.batch(513, 96, S, A)
+    ns, nt, nf = int(cfg["src_ratio"] * bs), int(cfg["trg_ratio"] * bs), int(cfg["fake_batch_scale"] * bs)
+    win = lambda rows, n: [x[(k * 13) % (96 - n + 1):][:n].copy() for x in rows]
+    parts = [win(src, ns), win(tar, nt), win(fake, nf)]
+    return tuple(np.concatenate([p[i] for p in parts], 0) for i in range(5)), ns + nt

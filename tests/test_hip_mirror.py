@@ -617,3 +617,51 @@ def test_writer_scalars_on_the_reference_cadence(dev, tmp_path):
     q12 = ops.mlp3_forward(pol.q_funcs.blob, S + A, 1, 2, b[0], b[1])
     close(torch.tensor(got["train/q1"][1]), q12[0].mean().cpu(), rtol=1e-5, atol=1e-6)
     close(torch.tensor(got["train/q_behavior"][1]), torch.minimum(q12[0], q12[1]).mean().cpu(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_mirror_tracks_the_reference_over_thirty_steps(mode, dev):
+    """g17: 30 reference train() steps on rotating preset batches.  The mirror's losses follow the reference's step by step
+    and the final actor / twin-Q / target parameters agree -- in exact fp32 and in the bench's default bf16x3 mode."""
+    from mobody_amd.algo.offline_offline.mobody import MOBODY
+    from mobody_amd.algo import utils
+    g = gu.load("g17_train_trajectory")
+    S, A, bs, steps = int(g["S"]), int(g["A"]), int(g["bs"]), int(g["steps"])
+    cfg = gu.policy_cfg(S, A, mfma=mode)
+    pol = MOBODY(cfg, dev)
+    assert pol.mfma == mode
+    pa, pq, pv = gu.policy_params(int(g["seed"]), S, A)
+    pol.policy.load_state_dict({k: torch.from_numpy(v) for k, v in pa.items()})
+    pol.q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+    pol.target_q_funcs.load_state_dict({k: torch.from_numpy(v) for k, v in pq.items()})
+
+    def rotating(seed):
+        rows = gu.gi.batch(seed, 96, S, A)
+        rb = utils.ReplayBuffer(S, A, dev, max_size=96)
+        rb.convert_D4RL(dict(observations=rows[0], actions=rows[1], next_observations=rows[2], rewards=rows[3][:, 0],
+                             terminals=1.0 - rows[4][:, 0]))
+        calls = []
+
+        def draw(n):
+            k = len(calls); calls.append(n)
+            return torch.arange(n, dtype=torch.int32, device=dev) + (k * 13) % (96 - n + 1)
+        rb.draw_indices = draw
+        return rb
+
+    src, tar = rotating(511), rotating(512)
+    pol.fake_replay_buffer = rotating(513)
+    pol.total_it = 1
+    worst = 0.0
+    for k in range(steps):
+        pol.train(src, tar, bs, None, None)
+        q_loss, pi_loss, bc_loss = pol.losses()
+        close(q_loss, g["q_loss"][k], rtol=1e-4, atol=0)
+        close(pi_loss, g["pi_loss"][k], rtol=2e-4, atol=5e-5)
+        close(bc_loss, g["bc_loss"][k], rtol=2e-4, atol=5e-5)
+        worst = max(worst, abs(pi_loss - float(g["pi_loss"][k])) / abs(float(g["pi_loss"][k])))
+    assert pol.total_it == steps + 1 and pol.q_optimizer.t == steps
+    # parameters after 30 Adam steps of lr 3e-4: within 2 % of one step's movement
+    for nm, net in (("q", pol.q_funcs), ("actor", pol.policy), ("qt", pol.target_q_funcs)):
+        for k_, v in net.state_dict().items():
+            close(gu.sub(v.cpu().numpy()), g[f"final_{nm}_p::{k_}"], rtol=1e-4, atol=6e-6)
+    print(f"[{mode}] worst relative pi_loss deviation over {steps} steps: {worst:.2e}")

@@ -116,6 +116,24 @@ def test_g7_train_step(tag):
                 close(gu.sub(v.numpy()), g[f"s{step}_{nm}_p::{k}"], rtol=1e-5, atol=1e-6)
 
 
+def test_g17_thirty_step_trajectory():
+    """The CPU restatement tracks the reference over 30 optimizer steps (Adam moments / bias corrections / Polyak)."""
+    g = gu.load("g17_train_trajectory")
+    S, A, bs, steps = int(g["S"]), int(g["A"]), int(g["bs"]), int(g["steps"])
+    cfg = gu.policy_cfg(S, A)
+    pa, pq, pv = gu.policy_params(int(g["seed"]), S, A)
+    st = O.TrainState(pa, pq, pv)
+    for k in range(steps):
+        batch, n_true = gu.g17_batch(k, cfg, bs, S, A)
+        out = O.train_step(st, batch, n_true, cfg)
+        close(out["q_loss"], g["q_loss"][k], rtol=2e-5)
+        close(out["pi_loss"], g["pi_loss"][k], rtol=5e-5, atol=5e-6)
+        close(out["bc_loss"], g["bc_loss"][k], rtol=5e-5, atol=5e-6)
+    for nm, params in (("q", st.q), ("actor", st.actor), ("qt", st.q_targ)):
+        for k_, v in params.items():
+            close(gu.sub(v.numpy()), g[f"final_{nm}_p::{k_}"], rtol=1e-4, atol=2e-6)
+
+
 def test_g8_ring_append_and_sample():
     g = gu.load("g8_replay")
     cap, S, A = 50, 5, 2
