@@ -8,7 +8,7 @@
 // reward | not_done contiguous, rows `pitch` floats apart, pitch a multiple of 16 floats = 64 bytes) is what the mirror's
 // ReplayBuffer allocates -- a random row is then three aligned 64-byte sectors (S=17, A=6: 168 of 192 bytes useful) read or
 // written with 16-byte accesses; five separate arrays (pitch 0, the reference's field-per-array shape) cost five random
-// pieces of 4..68 bytes per row, ~2.8x the useful bytes at S=17.  Both kernels stage 16 rows per workgroup in LDS so the
+// pieces of 4..68 bytes per row, three times the fetch requests of the ring at S=17.  Both kernels stage 16 rows per workgroup in LDS so the
 // batch side (contiguous [N][S] / [N][A] / [N] arrays) is read and written fully coalesced.
 #include "common.h"
 #include "rng.h"
