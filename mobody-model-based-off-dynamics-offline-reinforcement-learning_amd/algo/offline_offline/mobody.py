@@ -307,8 +307,11 @@ class MOBODY(object):
                                         (cls.sa_classifier, cls.opt_sa, dz_sa, x_sa, h1a, h2a)):
             self._cls_ws = ops.mlp3_backward(net.blob_T, net.in_dim, 2, 1, dz, x, h1, h2, opt.grad,
                                              getattr(self, "_cls_ws", None))
-            opt.step()
-        return loss[0], loss[1]                           # (loss_sa, loss_sas) as device scalars
+            world = self._world()
+            if world > 1:         # the losses are means over the rank's rows -> global mean = sum / world
+                torch.distributed.all_reduce(opt.grad)
+            opt.step(grad_scale=1.0 / world)
+        return loss[0], loss[1]                           # (loss_sa, loss_sas) as device scalars (the rank's share)
 
     def _dara_delta(self, s, a, s2, reward=None, coef=0.0):
         """Noise-free classifier pass + the DARC/DARA log-ratio penalty; adds coef*delta to `reward` in place."""

@@ -138,3 +138,62 @@ def test_segment_replay_with_rccl_process_group_single_rank(tmp_path):
     for k in r["single"]:
         assert torch.equal(r["single"][k], r["segments"][k]), k
         assert torch.equal(r["single"][k], r["captured"][k]), k       # RCCL all-reduces captured inside the one graph
+
+
+def _dara_rows(S, A):
+    """Global classifier batch of 64 source + 64 target rows with its input noise, and the way two ranks split it."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+    import golden_util as gu
+    src, tar = gu.gi.batch(71, 64, S, A), gu.gi.batch(72, 64, S, A)
+    rng = np.random.default_rng(5)
+    n_sas = rng.standard_normal((128, 2 * S + A)).astype(np.float32)
+    n_sa = rng.standard_normal((128, S + A)).astype(np.float32)
+
+    def pick(lo_src, hi_src):                        # rows [src[lo:hi] | tar[lo:hi]] and the matching noise rows
+        sel = np.r_[lo_src:hi_src, 64 + lo_src:64 + hi_src]
+        rows = [np.concatenate([src[k][lo_src:hi_src], tar[k][lo_src:hi_src]], 0) for k in (0, 1, 2)]
+        return rows, n_sas[sel], n_sa[sel]
+    return pick
+
+
+def _dara_worker(rank, world, port, tmp):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")]
+    import torch.distributed as dist
+    import golden_util as gu
+    from mobody_amd.algo.call_algo import call_algo
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    S, A = 17, 6
+    cfg = gu.policy_cfg(S, A, rng="device", seed=0, penalty_type="dara")
+    torch.manual_seed(9 if world == 1 else rank)                  # ranks start from different weights; rank 0's == the single run's
+    if world > 1 and rank == 0:
+        torch.manual_seed(9)
+    pol = call_algo("mobody", cfg, 3, dev)
+    pol.sync_replicas()
+    pick = _dara_rows(S, A)
+    lo, hi = (0, 64) if world == 1 else (32 * rank, 32 * rank + 32)
+    rows, n_sas, n_sa = pick(lo, hi)
+    td = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    for _ in range(3):
+        pol.update_classifier(None, None, hi - lo, rows=tuple(td(r) for r in rows), noise=(td(n_sas), td(n_sa)))
+    torch.cuda.synchronize()
+    torch.save({k: v.cpu() for k, v in pol.classifier.state_dict().items()}, os.path.join(tmp, f"dara_w{world}_r{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_dara_classifier_update_equals_the_single_rank_update(tmp_path):
+    """with world > 1 the classifier gradients are all-reduced, so two ranks that each see half of the
+    rows (32 source + 32 target) make exactly the update one rank makes on all 128."""
+    port = 29900 + os.getpid() % 90
+    mp.spawn(_dara_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_dara_worker, args=(1, port + 1, str(tmp_path)), nprocs=1, join=True)
+    r0, r1, one = (torch.load(tmp_path / f) for f in ("dara_w2_r0.pt", "dara_w2_r1.pt", "dara_w1_r0.pt"))
+    for k in one:
+        assert torch.equal(r0[k], r1[k]), k                                        # replicas in sync
+        # the two sums are formed in different orders; Adam's 1/sqrt(v) stretches that on near-zero-gradient entries: 2e-6 = 0.2 % of a step
+        np.testing.assert_allclose(r0[k].numpy(), one[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+    assert any(float((one[k] - one[k].mean()).abs().max()) > 0 for k in one)
