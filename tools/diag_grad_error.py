@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np, torch
 import golden_util as gu
 from oracle import mobody_oracle as O
-from test_hip_train import Engine
+from mobody_amd.engine import Engine
 
 # usage: diag_grad_error.py [S A N Nt]   (default: the golden g7 batch, bs=32)
 if len(sys.argv) == 5:

@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "
 import numpy as np, torch
 import golden_util as gu
 from mobody_amd import ops, packing
-from test_hip_train import Engine
+from mobody_amd.engine import Engine
 
 dev = torch.device("cuda:0")
 for name, S, A, N, Nt, task in (("C2 walker", 17, 6, 10240, 8192, 4), ("C3 halfcheetah", 17, 6, 40960, 32768, 1),
