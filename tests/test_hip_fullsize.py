@@ -245,3 +245,35 @@ def test_million_row_ring_wraps_and_gather_draws(dev):
     idx = O.rng_index(1234, 3, 7, n, cap)
     assert (out[0].cpu().numpy() == want[idx][:, None]).all()
     assert (out[3].cpu().numpy()[:, 0] == want[idx]).all()
+
+
+@pytest.mark.parametrize("layout", ["ring", "arrays"])
+def test_large_filtered_append_wraps_bit_exact(dev, layout):
+    """100 000-row appends with a random keep mask (25 scan blocks of 4 096 rows, 64-row scatter workgroups) into a
+    150 000-row ring that wraps: every kept row lands where add_batch's slice arithmetic puts it (utils.py:43-92)."""
+    from mobody_amd import ops
+    rng = np.random.default_rng(31)
+    S, A, cap, M = 17, 6, 150000, 100000
+    if layout == "ring":
+        buf = ops.RingView(torch.zeros(cap, ops.ring_pitch(S, A), device=dev), S, A)
+    else:
+        buf = tuple(torch.zeros(cap, n, device=dev) for n in (S, A, S, 1, 1))
+    ps = torch.zeros(2, dtype=torch.int64, device=dev)
+    ref = [np.zeros((cap, n), np.float32) for n in (S, A, S, 1, 1)]
+    ptr = size = 0
+    td = lambda x: torch.from_numpy(x).to(dev).contiguous()
+    for step in range(3):
+        rows = [rng.standard_normal((M, n)).astype(np.float32) for n in (S, A, S, 1)]
+        term = (rng.uniform(size=(M, 1)) > 0.7).astype(np.uint8)
+        keep = (rng.uniform(size=M) > (0.1, 0.5, 0.3)[step]).astype(np.uint8)
+        ops.ring_append(buf, cap, ps, S, A, td(rows[0]), td(rows[1]), td(rows[2]), td(rows[3]), td(term), td(keep))
+        sel = keep.astype(bool)
+        kept = [r[sel] for r in rows] + [1.0 - term[sel].astype(np.float32)]
+        segs, ptr, size = O.ring_append_plan(ptr, size, cap, int(sel.sum()))
+        for dst, src, ln in segs:
+            for d_, s_ in zip(ref, kept):
+                d_[dst:dst + ln] = s_[src:src + ln]
+        assert ps.cpu().tolist() == [ptr, size], step
+    assert size == cap                                                      # wrapped
+    for t, want in zip(buf, ref):
+        assert (t.cpu().numpy() == want).all()
