@@ -368,7 +368,7 @@ def main():
 
     # the other MFMA modes, 100 steps each on the same buffers (extra information; the headline is args.mfma)
     sweep = {}
-    if not args.no_mode_sweep:
+    if not args.no_mode_sweep and world == 1:             # single GPU only: the scaling runs time the headline mode alone
         for mode in ("f32", "bf16x3", "bf16x2", "bf16"):
             if mode == args.mfma:
                 continue
