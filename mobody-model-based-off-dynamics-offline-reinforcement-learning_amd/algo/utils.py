@@ -60,7 +60,29 @@ class ReplayBuffer(object):
         """`store` [rows][pitch] becomes the storage; state / action / next_state / reward / not_done are views of it."""
         self.store = store
         self._view = ops.RingView(store, self.state_dim, self.action_dim)
-        self.state, self.action, self.next_state, self.reward, self.not_done = self._view.fields()
+
+    # The five public attributes (utils.py:19-23).  Reading gives the column view of the store; ASSIGNING -- the reference's
+    # driver and MOBODY do both `buf.reward -= 1.0` (train_mobody.py:551,557) and `buf.reward = new_rewards` (mobody.py:381) --
+    # writes the values into the store, so the kernels (which read the store) see them.
+    def _get_field(self, k):
+        return self._view.fields()[k]
+
+    def _set_field(self, k, value):
+        view = self._view.fields()[k]
+        t = value if isinstance(value, torch.Tensor) else torch.as_tensor(np.asarray(value))
+        if t.device == view.device and t.data_ptr() == view.data_ptr() and t.shape == view.shape and t.stride() == view.stride():
+            return                                   # `buf.reward -= 1.0` hands the (already updated) view back
+        t = t.to(device=self.device, dtype=torch.float32).reshape(-1, view.shape[1])
+        if t.shape[0] != view.shape[0]:
+            raise ValueError(f"ReplayBuffer.{FIELDS[k]}: {t.shape[0]} rows assigned to a {view.shape[0]}-row buffer "
+                             "(use convert_D4RL to adopt a dataset of another size)")
+        view.copy_(t)
+
+    state = property(lambda self: self._get_field(0), lambda self, v: self._set_field(0, v))
+    action = property(lambda self: self._get_field(1), lambda self, v: self._set_field(1, v))
+    next_state = property(lambda self: self._get_field(2), lambda self, v: self._set_field(2, v))
+    reward = property(lambda self: self._get_field(3), lambda self, v: self._set_field(3, v))
+    not_done = property(lambda self: self._get_field(4), lambda self, v: self._set_field(4, v))
 
     def _fields(self):
         return self._view

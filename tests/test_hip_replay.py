@@ -208,3 +208,24 @@ def test_ring_layout_row_padding_and_wide_rows(dev, S, A):
     o1, o2 = ops.gather_batch([bufs[0]], [idx], S, A), ops.gather_batch([bufs[1]], [idx], S, A)
     for x, y in zip(o1, o2):
         assert torch.equal(x, y)
+
+
+def test_replay_buffer_attribute_assignment_reaches_the_store(dev):
+    """The reference mutates the public fields both ways: `buf.reward -= 1.0` (train_mobody.py:551,557) and
+    `buf.reward = new_rewards` (mobody.py:381).  Either must be what sample() returns afterwards."""
+    from mobody_amd.algo import utils
+    rng = np.random.default_rng(8)
+    S, A, n = 5, 2, 40
+    rb = utils.ReplayBuffer(S, A, dev, max_size=n)
+    rows = [rng.standard_normal((n, k)).astype(np.float32) for k in (S, A, S)]
+    rb.convert_D4RL(dict(observations=rows[0], actions=rows[1], next_observations=rows[2],
+                         rewards=np.arange(n, dtype=np.float32), terminals=np.zeros(n, bool)))
+    rb.draw_indices = lambda k: torch.arange(k, dtype=torch.int32, device=dev)
+    rb.reward -= 1.0
+    assert (rb.sample(n)[3].cpu().numpy()[:, 0] == np.arange(n) - 1.0).all()
+    rb.reward = torch.full((n, 1), 7.0)                          # a new CPU tensor, as mobody.py:381 assigns
+    assert (rb.sample(n)[3].cpu().numpy() == 7.0).all() and (rb.store[:, 2 * S + A] == 7.0).all()
+    rb.state = rows[2]                                           # numpy array
+    assert (rb.sample(n)[0].cpu().numpy() == rows[2]).all()
+    with pytest.raises(ValueError):
+        rb.reward = torch.zeros(n + 1, 1)
