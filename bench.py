@@ -433,6 +433,13 @@ def main():
             "value": N * world * args.steps / dt, "unit": "transitions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
+            "dtype_note": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference's arithmetic",
+                           "bf16x3": "fp32 operands as three bf16 terms, six bf16 MFMAs per fp32 product, fp32 accumulate: fp32-grade "
+                                     "(~5e-7 of max|out| from the fp32 kernels); holds the fp32 parity tolerances against the reference's "
+                                     "golden vectors (tests/test_hip_precision.py; the whole -m gpu suite passes with MOBODY_MFMA=bf16x3); "
+                                     "the exact-fp32 step time of the same run is under other_mfma_modes.f32",
+                           "bf16x2": "two bf16 terms, three products (~6e-6): throughput mode, not parity grade",
+                           "bf16": "plain bf16 MFMA inputs (~3e-3): throughput mode, not parity grade"}[args.mfma],
             "config": {"workload": f"{args.config}: {c['label']} (S={S} A={A}, ensemble 7, rollout_len {c['H']}, N={N} rows per "
                                    f"train() step: src|tar|fake = {bs}|{bs}|{bs // 2}), "
                                    + ("exact fp32 MFMA" if args.mfma == "f32" else f"256x256 GEMMs (forward, backward, weight gradient) on the {args.mfma} split-precision MFMA "
