@@ -135,8 +135,9 @@ class MOBODYEnsembleDynamics(object):
         d = torch.distributed
         return (d.get_world_size(), d.get_rank()) if d.is_available() and d.is_initialized() else (1, 0)
 
-    def _learn_batch(self, use_trg, xenc, act, rew, b, b_global):
-        """One optimizer step on the rows already laid out as the kernels want them (zero_grad, backward, Adam.step)."""
+    def _learn_batch(self, use_trg, xenc, act, rew, b, b_global, lo_rel=0):
+        """One optimizer step on the rows already laid out as the kernels want them (zero_grad, backward, Adam.step).
+        Data parallel: this rank holds rows [lo_rel, lo_rel + b) of the batch's b_global rows."""
         m = self.model
         st = m.train_state()
         S, A = m.obs_dim, m.action_dim
@@ -144,7 +145,9 @@ class MOBODYEnsembleDynamics(object):
         self._train_calls += 1
         n6 = n7 = None
         if self.train_noise_fn is not None:
-            n6, n7 = self.train_noise_fn(b)
+            n6, n7 = self.train_noise_fn(b_global)        # the noise of the WHOLE batch on every rank (one stream), then this
+            if b != b_global:                             # rank's rows of it: N ranks == one rank on the same batch
+                n6, n7 = n6[:, :, lo_rel:lo_rel + b].contiguous(), n7[:, lo_rel:lo_rel + b].contiguous()
         world, _ = self._world()
         if b > 0:
             ops.pretrain_grads(S, A, b, use_trg, self.encoder_loss_coef, st["blob"], st["blob_T"], xenc, act, rew, st["grad"],
@@ -258,7 +261,7 @@ class MOBODYEnsembleDynamics(object):
             lo, b = self._shard(start, rows)
             sl = slice(lo, lo + b)
             xenc = torch.cat([s[:, sl], s2[:, sl]], 1).contiguous()
-            return self._learn_batch(use_trg_data, xenc, a[:, sl].contiguous(), r[:, sl].contiguous(), b, rows)
+            return self._learn_batch(use_trg_data, xenc, a[:, sl].contiguous(), r[:, sl].contiguous(), b, rows, lo - start)
 
         return self._learn_loop(s.shape[1], batch_size, step)
 
@@ -271,11 +274,11 @@ class MOBODYEnsembleDynamics(object):
         def step(start, rows):
             lo, b = self._shard(start, rows)
             if b == 0:
-                return self._learn_batch(use_trg, None, None, None, 0, rows)
+                return self._learn_batch(use_trg, None, None, None, 0, rows, lo - start)
             xenc, act, rew = ops.pretrain_gather(data[0], data[1], data[2], data[3], idx, lo, b)
             if world == 1:
                 return self._learn_batch_fused(use_trg, xenc, act, rew, b)
-            return self._learn_batch(use_trg, xenc, act, rew, b, rows)
+            return self._learn_batch(use_trg, xenc, act, rew, b, rows, lo - start)
 
         n = idx.shape[1]
         n_full = n // batch_size
@@ -338,8 +341,10 @@ class MOBODYEnsembleDynamics(object):
         s_tr, s_ho = split(range(n_src), (n_src - src_hold, src_hold))                      # :765-769
         t_tr, t_ho = split(range(n_trg), (n_trg - trg_hold, trg_hold))
         world, _ = self._world()
+        if world > 1:                                     # data parallel: every rank trains rank 0's model ...
+            self.model.broadcast_(torch.distributed)
 
-        def bc(t):                                        # data parallel: every rank follows rank 0's index streams
+        def bc(t):                                        # ... on rank 0's index streams
             if world > 1:
                 torch.distributed.broadcast(t, 0)
             return t

@@ -334,3 +334,53 @@ def test_pretrain_graph_replay_equals_eager_fused_steps(dev):
     for k, v in tr.unpack(tr.blob, full2).items():
         # (the CPU twin of the Philox normals agrees with the device to ~2e-6, and Adam's first step is sign-like)
         np.testing.assert_allclose(got[k].cpu().numpy(), v.cpu().numpy(), rtol=2e-5, atol=5e-6, err_msg=k)
+
+
+def _dp_train_worker(rank, world, port, tmp):
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden")]
+    import torch.distributed as dist
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = gu.load("g13_dyn_train")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    dyn, m = _mirror_dynamics(gu.dyn_params_for(g), S, A, dev)
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    td = lambda x: torch.from_numpy(x).to(dev)
+
+    def noise(b):                                       # called with the WHOLE batch's row count on every rank
+        nz = noise7(rng, b, S)
+        return td(np.stack(nz[:6])), td(nz[6])
+
+    dyn.train_noise_fn = noise
+    src = gu.gi.batch(901, int(g["n_src"]), S, A); trg = gu.gi.batch(902, int(g["n_trg"]), S, A)
+    torch.manual_seed(int(g["rng_seed"]) + 100 * rank); np.random.seed(int(g["rng_seed"]) + 100 * rank)   # rank 0's streams rule
+    if rank == 0:
+        torch.manual_seed(int(g["rng_seed"])); np.random.seed(int(g["rng_seed"]))
+    dyn.train(tuple(torch.from_numpy(x) for x in src), tuple(torch.from_numpy(x) for x in trg), max_epochs=2, batch_size=bs)
+    got = []
+    for h in dyn.history:
+        got += [h["src_val"], h["trg_val"]]
+    torch.save(dict(val=np.array(got), steps=dyn.total_steps, elites=[int(x) for x in m.elites.tolist()],
+                    sd={k: v.cpu() for k, v in m.state_dict().items()}), os.path.join(tmp, f"dp_train_r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_dynamics_train_vs_reference_golden(tmp_path):
+    """The same g13 run on TWO ranks (each batch's rows split between them, one gradient all-reduce per step, rank 0's
+    index streams broadcast, the explicit noise stream sliced per rank): replicas identical, and the run still
+    reproduces the reference's single-process validation losses, step count and elites."""
+    import os
+    import torch.multiprocessing as mp
+    port = 29800 + os.getpid() % 90
+    mp.spawn(_dp_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"dp_train_r{r}.pt", weights_only=False) for r in (0, 1))
+    g = gu.load("g13_dyn_train")
+    assert r0["steps"] == r1["steps"] == int(g["total_steps"]) and r0["elites"] == r1["elites"]
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), k
+    close(r0["val"], g["validate"][:, 0], rtol=1e-4, atol=1e-8)
+    assert sorted(r0["elites"]) == sorted(int(x) for x in g["elites"])
