@@ -142,3 +142,32 @@ def test_cli_real_dataset_mode_without_simulators(tmp_path, capsys):
     with pytest.raises(ValueError):
         tm.main(["--policy", "MOBODY", "--env", "ant-friction", "--mode", "3", "--synthetic", "0",
                  "--src_data", str(tmp_path / "src.npz"), "--tar_data", str(tmp_path / "tar.npz")])
+
+
+def test_scalar_log_and_dataset_loading_on_the_host(tmp_path):
+    """The CLI's CSV writer (SummaryWriter.add_scalar surface) and the --synthetic 0 dataset loader, without a GPU."""
+    import argparse
+    import numpy as np
+    import torch
+    from mobody_amd import train_mobody as tm
+    w = tm.ScalarLog(str(tmp_path / "tb" / "scalars.csv"))
+    w.add_scalar("train/q1", torch.tensor(1.5), 5000)
+    w.add_scalar("test/model error reward", 0.25, global_step=10)
+    w.close()
+    rows = [l.strip().split(",") for l in open(w.path)]
+    assert rows == [["tag", "step", "value"], ["train/q1", "5000", "1.5"], ["test/model error reward", "10", "0.25"]]
+    rng = np.random.default_rng(0)
+    n, m, S, A = 20, 11, 17, 6
+    np.savez(tmp_path / "src.npz", observations=rng.standard_normal((n, S)), actions=rng.standard_normal((n, A)),
+             next_observations=rng.standard_normal((n, S)), rewards=rng.standard_normal(n), terminals=np.zeros(n, bool))
+    tobs = rng.standard_normal((m, S)).astype(np.float32)
+    np.savez(tmp_path / "tar.npz", observations=tobs, actions=rng.standard_normal((m, A)), rewards=rng.standard_normal((m, 1)),
+             terminals=np.zeros(m, bool), timeouts=np.zeros(m, bool))
+    args = argparse.Namespace(src_data=str(tmp_path / "src.npz"), tar_data=str(tmp_path / "tar.npz"), env="walker2d-friction",
+                              shift_level=2.0, tartype="medium")
+    src, tar = tm.load_datasets(args)
+    assert src["observations"].shape == (n, S) and tar["observations"].shape == (m - 1, S)
+    assert (tar["next_observations"] == tobs[1:]).all() and tar["rewards"].shape == (m - 1,)       # shift by one, [N,1] flattened
+    args.src_data = None
+    with pytest.raises(NotImplementedError):
+        tm.load_datasets(args)
