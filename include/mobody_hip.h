@@ -139,6 +139,18 @@ int mobody_dyn_step(const float* dyn_blob, const float* dyn_planes, int precisio
                     uint8_t* terminal, float* penalty, float* raw_reward, float* mean_out, float* workspace,
                     void* stream);
 
+/* The same step for the MOPO ablation (config['mopo'] = 1, mobody_module.py:114-118,218-219,251-254,264-266,288-289): the
+ * ensemble means are obs + MLP_e([obs, act]) with the 7-member Swish MLP za_src1..3 (S+A -> 256 -> 256 -> S) packed as
+ * mobody_mlp_layout(S + A, S, 7) (mopo_blob; mopo_blob_T from mobody_mlp_transpose, needed when precision != 0);
+ * encoders / decoder are bypassed and forward_trg == forward_src, so there is no use_trg.  The reward head is read
+ * from dyn_blob exactly as in mobody_dyn_step; every other argument has the same meaning. */
+int mobody_mopo_step(const float* dyn_blob, const float* dyn_planes, const float* mopo_blob, const float* mopo_blob_T,
+                     int precision, int S, int A, int task, const float* obs, const float* act, int64_t B,
+                     const float* noise, const int32_t* elite_idx, const uint8_t* alive, const int32_t* elites,
+                     int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty, float* next_obs,
+                     float* reward, uint8_t* terminal, float* penalty, float* raw_reward, float* mean_out,
+                     float* workspace, void* stream);
+
 /* ---- replay buffer views (used by the rollout below and by the gather / append entry points) ---- */
 typedef struct MobodyBufferView {   /* ReplayBuffer fields, algo/utils.py:19-23 */
   const float* state; const float* action; const float* next_state; const float* reward; const float* not_done;

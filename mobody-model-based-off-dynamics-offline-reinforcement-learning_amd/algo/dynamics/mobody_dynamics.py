@@ -94,7 +94,8 @@ class MOBODYEnsembleDynamics(object):
                             seed=(self.seed + dp.rank_salt()) & 0xFFFFFFFF, call=self._calls,
                             penalty_coef=float(self._penalty_coef or 0.0),
                             use_penalty=bool(use_penalty), use_trg=bool(use_trg), want_mean=want_mean,
-                            workspace=self._ws, planes=m.planes() if self.precision else None, precision=self.precision)
+                            workspace=self._ws, planes=m.planes() if self.precision else None, precision=self.precision,
+                            mopo=m.packed_mopo() if getattr(m, "mopo", False) else None)
 
     @torch.no_grad()
     def step(self, obs, action, use_penalty=True, use_trg=True):

@@ -27,8 +27,9 @@ class MOBODYModule(object):
         if int(hidden_dims) != 256 or int(num_ensemble) != 7:
             raise ValueError("the MI355X kernels are built for hidden_dims=256, num_ensemble=7 (reference defaults)")
         self.config = config or {}
-        if self.config.get("mopo") or self.config.get("latent_reward"):
-            raise NotImplementedError("mopo / latent_reward ablations are outside the accelerated path")
+        if self.config.get("latent_reward"):
+            raise NotImplementedError("the latent_reward ablation is outside the accelerated path")
+        self.mopo = bool(self.config.get("mopo"))        # MOPO ablation: a plain ensemble MLP s + f(s, a) (:114-118,133-137)
         self.obs_dim, self.action_dim = int(obs_dim), int(action_dim)
         self.num_ensemble, self.num_elites = 7, int(num_elites)
         self.device = torch.device("cuda" if str(device) == "cpu" and torch.cuda.is_available() else device)
@@ -41,6 +42,15 @@ class MOBODYModule(object):
                     za_de_src1=(LATENT, 8), za_de_src2=(8, A), za_trg1=(LATENT + A, 32), za_trg2=(32, 2 * LATENT),
                     za_de_trg1=(LATENT, 8), za_de_trg2=(8, A), transition1=(LATENT, H), transition2=(H, H),
                     transition3=(H, S), reward_model1=(2 * S + A, H), reward_model2=(H, H), reward_model3=(H, 2))
+        if self.mopo:                                             # same module_list order as the reference (:114-118,133-137)
+            order = []
+            for name, io in dims.items():
+                order.append((name, io))
+                if name in ("za_src2", "za_trg2"):
+                    order.append((name[:-1] + "3", (H, S)))
+            dims = dict(order)
+            for pre in ("za_src", "za_trg"):
+                dims[pre + "1"], dims[pre + "2"] = (S + A, H), (H, H)
         self._p = {}
         for name, (i, o) in dims.items():                         # EnsembleLinear.__init__ :371-389
             w = torch.empty(7, i, o, device=self.device)
@@ -54,7 +64,7 @@ class MOBODYModule(object):
         self._p["max_logvar_latent"] = torch.ones(LATENT, device=self.device) * 20
         self._p["min_logvar_latent"] = torch.ones(LATENT, device=self.device) * -20
         self._p["elites"] = torch.arange(self.num_elites, device=self.device)
-        self._blob, self._planes = None, None
+        self._blob, self._planes, self._mopo = None, None, None
         self._train, self._train_ahead = None, False
         self.layer_names = list(dims)                              # module_list order, mobody_module.py:97-150
 
@@ -136,6 +146,9 @@ class MOBODYModule(object):
     # ---- training blob (dynamics pre-training) ----
     def train_state(self):
         """dict(blob, blob_T, grad, m, v, t_main, t_za={False: .., True: ..}) of the packed training copy."""
+        if self.mopo:
+            raise NotImplementedError("pre-training with config['mopo'] = 1 is outside the accelerated path "
+                                      "(inference / rollouts / checkpoints of such a model are supported)")
         if self._train is None:
             blob = packing.pack_pretrain(self._p, self.obs_dim, self.action_dim, self.device)
             z = lambda: torch.zeros_like(blob)
@@ -165,9 +178,30 @@ class MOBODYModule(object):
     def packed(self):
         self._sync_from_train()
         if self._blob is None:
-            self._blob = packing.pack_dynamics(self._p, self.obs_dim, self.action_dim, self.device)
-            self._planes = None
+            p = self._p
+            if self.mopo:                               # the encoder slots of the layout are unused: zeros of their latent shapes
+                p = dict(p)
+                A = self.action_dim
+                for pre in ("za_src", "za_trg"):
+                    for n_, (i, o) in ((pre + "1", (LATENT + A, 32)), (pre + "2", (32, 2 * LATENT))):
+                        p[n_ + ".weight"] = torch.zeros(7, i, o, device=self.device)
+                        p[n_ + ".bias"] = torch.zeros(7, 1, o, device=self.device)
+            self._blob = packing.pack_dynamics(p, self.obs_dim, self.action_dim, self.device)
+            self._planes, self._mopo = None, None
         return self._blob
+
+    def packed_mopo(self):
+        """(blob, blob_T) of the MOPO ablation's 7-member MLP za_src1..3 in mobody_mlp_layout(S + A, S, 7) (EnsembleLinear
+        weights are [in, out]; the generic packer takes nn.Linear's [out, in])."""
+        self.packed()
+        if self._mopo is None:
+            S, A = self.obs_dim, self.action_dim
+            members = [{f"network.{li}.weight": self._p[f"za_src{k}.weight"][e].t().contiguous()
+                        for li, k in ((0, 1), (2, 2), (4, 3))} | {f"network.{li}.bias": self._p[f"za_src{k}.bias"][e, 0]
+                                                                   for li, k in ((0, 1), (2, 2), (4, 3))} for e in range(7)]
+            blob = packing.pack_mlp(members, S + A, S, self.device)
+            self._mopo = (blob, ops.mlp_transpose(blob, S + A, S, 7))
+        return self._mopo
 
     def planes(self):
         """bf16 planes of the three 256 x 256 layers (split-precision modes), rebuilt with the packed blob."""
@@ -178,6 +212,15 @@ class MOBODYModule(object):
 
     def _fwd(self, state, action, use_trg):
         prec = ops.prec_id(self.config.get("mfma", ops.default_mfma()))
+        if self.mopo:                                   # s + f(s, a): forward_trg == forward_src (:264-266)
+            s = torch.as_tensor(state, dtype=torch.float32).to(self.device).contiguous()
+            a = torch.as_tensor(action, dtype=torch.float32).to(self.device).reshape(-1, self.action_dim).contiguous()
+            B = s.shape[0]                              # the means of one mopo step (zero noise, member 0 picked: both unused here)
+            r = ops.dyn_step(self.packed(), self.obs_dim, self.action_dim, 0, s, a,
+                             noise=torch.zeros(7, B, self.obs_dim, device=self.device),
+                             elite_idx=torch.zeros(B, dtype=torch.int32, device=self.device), want_mean=True,
+                             planes=self.planes() if prec else None, precision=prec, mopo=self.packed_mopo())
+            return r["mean"], None, None
         mean = ops.dyn_forward(self.packed(), self.obs_dim, self.action_dim, state, action, use_trg,
                                planes=self.planes() if prec else None, precision=prec)
         return mean, None, None        # (mean, zs_mu, zs_logvar): the latent stats are unused by the hot path

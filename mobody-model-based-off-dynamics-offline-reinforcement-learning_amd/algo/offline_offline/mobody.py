@@ -387,10 +387,10 @@ class MOBODY(object):
         t_idx = tar_rb.draw_indices(REFRESH_TAR)
         src = ops.gather_batch([src_rb._fields()], [s_idx], self.S, self.A)
         tar = ops.gather_batch([tar_rb._fields()], [t_idx], self.S, self.A)
-        if self.rng == "device":
+        if self.rng == "device" and not getattr(getattr(self.dynamics, "model", None), "mopo", False):
             self._rollout_into_fake(src[0], cfg["src_rollout_length"])
             self._rollout_into_fake(tar[0], cfg["trg_rollout_length"])
-        else:
+        else:                                  # NumPy-RNG parity mode, and the mopo ablation (host loop over mobody_mopo_step)
             tr, _ = self.rollout(src[0], cfg["src_rollout_length"])
             self.fake_replay_buffer.add_batch(tr)
             tr, _ = self.rollout(tar[0], cfg["trg_rollout_length"])

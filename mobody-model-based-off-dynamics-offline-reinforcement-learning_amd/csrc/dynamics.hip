@@ -372,7 +372,12 @@ extern "C" int64_t mobody_dyn_step_workspace(int S, int A, int64_t B) {
   return (int64_t)NENS * B * S + (int64_t)NENS * B;    // ensemble means + per-member reward means
 }
 
-static int dyn_step_impl(const float* dyn_blob, const float* dyn_planes, int precision, int S, int A, int task, const float* obs, const float* act,
+// mopo_blob != null: the MOPO ablation (config['mopo'], mobody_module.py:114-118,218-219,251-254,264-266,288-289) --
+// mean[e] = obs + MLP_e([obs, act]) with the 7-member Swish MLP (S+A -> 256 -> 256 -> S) za_src1..3 packed as
+// mobody_mlp_layout(S + A, S, 7); encoders and decoder are bypassed, forward_trg == forward_src.  Everything after the means
+// (std, sample, reward head, penalty, termination) is the same code.
+static int dyn_step_impl(const float* dyn_blob, const float* dyn_planes, const float* mopo_blob, const float* mopo_blob_T,
+                         int precision, int S, int A, int task, const float* obs, const float* act,
                          int64_t B, const float* noise, const int32_t* elite_idx, const uint8_t* alive,
                          const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty,
                          int use_trg, float* next_obs, float* reward, uint8_t* terminal, float* penalty,
@@ -393,7 +398,31 @@ static int dyn_step_impl(const float* dyn_blob, const float* dyn_planes, int pre
   float* r_mu = workspace + (int64_t)NENS * B * S;
   rc = check_dyn_prec("mobody_dyn_step", precision, dyn_planes);
   if (rc) return rc;
-  rc = launch_dyn_fwd(dyn_blob, L, obs, act, B, use_trg, mean, dyn_planes, precision, st);
+  if (mopo_blob != nullptr) {
+    MobodyMlpLayout ML;
+    rc = mobody_mlp_layout(S + A, S, NENS, &ML);
+    if (rc) return rc;
+    MB_REQUIRE(precision == 0 || mopo_blob_T != nullptr, "mobody_mopo_step: the split-precision modes need the T blob of the MLP");
+    Mlp3FwdArgs f{};
+    f.src[0] = obs; f.ld[0] = S; f.n[0] = S;
+    f.src[1] = act; f.ld[1] = A; f.n[1] = A;
+    f.w1 = mopo_blob + ML.w1; f.b1 = mopo_blob + ML.b1; f.w2 = mopo_blob + ML.w2; f.b2 = mopo_blob + ML.b2;
+    f.w3 = mopo_blob + ML.w3; f.b3 = mopo_blob + ML.b3;
+    f.sw1 = f.sb1 = f.sw2 = f.sb2 = f.sw3 = f.sb3 = ML.member_floats;
+    f.Kp1 = ML.Kp1; f.Np3 = ML.Np3; f.nout = S; f.rows = B;
+    f.out = mean; f.out_mstride = B * S; f.out_ld = S;
+    f.out_mode = 0; f.max_action = 1.f;
+    f.resid = obs; f.resid_ld = S;
+    if (precision == 0) {
+      rc = launch_mlp3_fwd(f, NENS, ACT_SWISH, st);
+    } else {
+      f.w2_planes = reinterpret_cast<const unsigned short*>(mopo_blob_T + ML.w2p);
+      f.planes_ms = 2 * ML.t_member_floats;
+      rc = launch_mlp3_fwd_bf(f, NENS, Mlp3FwdArgs{}, 0, ACT_SWISH, precision, st);
+    }
+  } else {
+    rc = launch_dyn_fwd(dyn_blob, L, obs, act, B, use_trg, mean, dyn_planes, precision, st);
+  }
   if (rc) return rc;
 
   DynSampleArgs sa{};
@@ -439,9 +468,21 @@ extern "C" int mobody_dyn_step(const float* dyn_blob, const float* dyn_planes, i
                                const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty,
                                int use_trg, float* next_obs, float* reward, uint8_t* terminal, float* penalty,
                                float* raw_reward, float* mean_out, float* workspace, void* stream) {
-  return dyn_step_impl(dyn_blob, dyn_planes, precision, S, A, task, obs, act, B, noise, elite_idx, alive, elites, n_elites, seed, call, penalty_coef,
-                       use_penalty, use_trg, next_obs, reward, terminal, penalty, raw_reward, mean_out, workspace, nullptr, nullptr,
-                       0.f, 0, stream);
+  return dyn_step_impl(dyn_blob, dyn_planes, nullptr, nullptr, precision, S, A, task, obs, act, B, noise, elite_idx, alive, elites, n_elites, seed,
+                       call, penalty_coef, use_penalty, use_trg, next_obs, reward, terminal, penalty, raw_reward, mean_out, workspace,
+                       nullptr, nullptr, 0.f, 0, stream);
+}
+
+extern "C" int mobody_mopo_step(const float* dyn_blob, const float* dyn_planes, const float* mopo_blob, const float* mopo_blob_T,
+                                int precision, int S, int A, int task, const float* obs, const float* act, int64_t B,
+                                const float* noise, const int32_t* elite_idx, const uint8_t* alive, const int32_t* elites,
+                                int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty, float* next_obs,
+                                float* reward, uint8_t* terminal, float* penalty, float* raw_reward, float* mean_out,
+                                float* workspace, void* stream) {
+  MB_REQUIRE(B == 0 || mopo_blob != nullptr, "mobody_mopo_step: null MLP blob");
+  return dyn_step_impl(dyn_blob, dyn_planes, mopo_blob, mopo_blob_T, precision, S, A, task, obs, act, B, noise, elite_idx, alive, elites,
+                       n_elites, seed, call, penalty_coef, use_penalty, 1, next_obs, reward, terminal, penalty, raw_reward, mean_out,
+                       workspace, nullptr, nullptr, 0.f, 0, stream);
 }
 
 // ---- whole H-step imagined rollout on the device (MOBODY.rollout + add_batch, mobody.py:596-657, utils.py:43-92) ----
@@ -508,7 +549,7 @@ extern "C" int mobody_rollout(const float* dyn_blob, const float* dyn_planes, co
     if (rc) return rc;
     // one imagined transition for every row; rows that terminated earlier keep their index and are flagged (alive mask);
     // the penalty filter and the alive update are formed in the sample kernel
-    rc = dyn_step_impl(dyn_blob, dyn_planes, precision, S, A, task, obs, w.act, B, nullptr, nullptr, t == 0 ? nullptr : w.alive, elites, n_elites, seed,
+    rc = dyn_step_impl(dyn_blob, dyn_planes, nullptr, nullptr, precision, S, A, task, obs, w.act, B, nullptr, nullptr, t == 0 ? nullptr : w.alive, elites, n_elites, seed,
                        call0 + (uint32_t)t, penalty_coef, use_penalty, use_trg, nxt, w.reward, w.terminal, w.penalty, nullptr, nullptr,
                        w.dyn, w.keep, w.alive, env_filter, filter_bad_rollout, stream);
     if (rc) return rc;

@@ -129,6 +129,8 @@ struct Mlp3FwdArgs {
   float* save_d1;           // [members][rows][256] Swish derivative at the pre-activations of layers 1 / 2 (training
   float* save_d2;           // forward of the ensemble nets only: k_mlp3_fwd_train)
   int out_mode;             // 0 raw, 1 max_action*tanh
+  const float* resid;       // optional: out[m][row][c] += resid[row*resid_ld + c] (shared by the members; mopo dynamics: s + f(s,a))
+  int resid_ld;
   float max_action;
 };
 

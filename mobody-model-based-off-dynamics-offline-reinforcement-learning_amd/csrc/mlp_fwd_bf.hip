@@ -62,6 +62,7 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
     if (row < rows_here && col < a.nout) {
       float y = v + bias;
       if (a.out_mode == 1) y = a.max_action * tanhf(y);
+      if (a.resid != nullptr) y += a.resid[(row0 + row) * a.resid_ld + col];
       out[row * a.out_ld + col] = y;
     }
   };

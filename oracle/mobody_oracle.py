@@ -93,8 +93,24 @@ def dyn_decode_transition(p, z):
     return _el(p, "transition3", t)
 
 
+def dyn_forward_mopo(p, obs, act):
+    """The MOPO ablation (config['mopo'] = 1): encode_state returns the state itself (:218-219), both action encoders are the
+    3-layer MLP za_src1..3 on [s, a] (:245-256,264-266), encode_transition is the identity (:288-289), so
+    forward_trg == forward_src == s + MLP_e([s, a])  (:315-330)."""
+    x = torch.cat([obs, act], -1)
+    g = swish(_el(p, "za_src1", x))
+    g = swish(_el(p, "za_src2", g))
+    return obs.unsqueeze(0) + _el(p, "za_src3", g), obs, obs
+
+
+def is_mopo(p):
+    return "za_src3.weight" in p
+
+
 def dyn_forward(p, obs, act, use_trg=True):
     """forward_trg / forward_src, mobody_module.py:315-330 -> (mean[E,B,S], zs_mu, zs_logvar)."""
+    if is_mopo(p):
+        return dyn_forward_mopo(p, obs, act)
     zs, zs_logvar = dyn_encode_state(p, obs)
     za = dyn_encode_action(p, zs, act, use_trg)
     return dyn_decode_transition(p, zs + za), zs, zs_logvar

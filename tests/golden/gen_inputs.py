@@ -33,14 +33,23 @@ def dyn_layer_dims(S, A):
     ]
 
 
-def dyn_params(seed, S, A, scale=1.0):
+def mopo_layer_dims(S, A):
+    """The EnsembleLinears of the MOPO ablation (config['mopo'] = 1): the action-encoder slots hold a plain 3-layer MLP
+    (mobody_module.py:114-118,133-137); the other layers exist but only the reward head is used."""
+    return [(n, i, o) for n, i, o in dyn_layer_dims(S, A) if not n.startswith("za_")] + \
+           [(pre + k, i, o) for pre in ("za_src", "za_trg") for k, i, o in (("1", S + A, H), ("2", H, H), ("3", H, S))]
+
+
+def dyn_params(seed, S, A, scale=1.0, mopo=False):
     rng = np.random.default_rng(seed)
     p = {}
-    for name, i, o in dyn_layer_dims(S, A):
+    for name, i, o in (mopo_layer_dims(S, A) if mopo else dyn_layer_dims(S, A)):
         p[name + ".weight"] = _w(rng, (E, i, o), scale / (2.0 * np.sqrt(i)))
         p[name + ".bias"] = _w(rng, (E, 1, o), 0.05)
     # spread the members apart so ensemble std / penalty are not tiny
     p["transition3.bias"] = p["transition3.bias"] + _w(rng, (E, 1, S), 0.05)
+    if mopo:
+        p["za_src3.bias"] = p["za_src3.bias"] + _w(rng, (E, 1, S), 0.05)
     return p
 
 

@@ -787,7 +787,57 @@ def g17():
     save("g17_train_trajectory", **out)
 
 
+# --------------------------------------------------------------------------- G18
+def g18():
+    """The MOPO ablation (config['mopo'] = 1): forward_trg / forward_src, step() in the four penalty / model flag
+    combinations, and a 3-step rollout through MOBODY.rollout, at walker and ant shapes."""
+    cfg_dyn = dict(DYN_CFG, mopo=1)
+    for tag, S, A, B, task, seed in (("walker", 17, 6, 48, "walker2d-medium-v2", 801), ("ant", 111, 8, 40, "ant-medium-v2", 802)):
+        p = gi.dyn_params(seed, S, A, mopo=True)
+        p["za_src3.bias"][:, 0, 0] += np.float32(-0.35 if tag == "walker" else -0.3)      # a few rows leave the alive box
+        m = MOBODYModule(S, A, 256, 7, 5, device="cpu", config=dict(cfg_dyn))
+        sd = m.state_dict()
+        for k, v in p.items():
+            assert sd[k].shape == v.shape, (k, sd[k].shape, v.shape)
+            sd[k] = torch.from_numpy(v)
+        m.load_state_dict(sd)
+        m.inference()
+        rng = np.random.default_rng(seed + 1000)
+        obs = gi.walker_like_obs(rng, B, S) if tag == "walker" else (0.6 * (np.arange(S) == 0) + 0.1 * rng.standard_normal((B, S))).astype(np.float32)
+        act = rng.uniform(-1, 1, (B, A)).astype(np.float32)
+        with torch.no_grad():
+            mt, _, _ = m.forward_trg(torch.from_numpy(obs), torch.from_numpy(act))
+            ms, _, _ = m.forward_src(torch.from_numpy(obs), torch.from_numpy(act))
+        out = dict(S=S, A=A, seed=seed, task=task, wsum=gi.checksum(p), obs=obs, act=act, mean_trg=mt.numpy(), mean_src=ms.numpy())
+        dyn = MOBODYEnsembleDynamics(dict(cfg_dyn), m, None, None, get_termination_fn(task), penalty_coef=0.1)
+        for up in (True, False):
+            for ut in (True, False):
+                np.random.seed(seed)
+                with RngTap(seed + 7) as tap:
+                    no, rw, term, info = dyn.step(torch.from_numpy(obs), torch.from_numpy(act), up, ut)
+                k = f"step_p{int(up)}_t{int(ut)}_"
+                out.update({k + "eps": tap.eps[0], k + "idx": tap.idx[0], k + "next_obs": no.numpy(), k + "reward": rw.numpy(),
+                            k + "terminal": term, k + "penalty": info["penalty"].numpy(), k + "raw_reward": info["raw_reward"].numpy()})
+        if tag == "walker":
+            cfg = policy_cfg(S, A, mopo=1)
+            pol, pa, _, _ = make_policy(cfg, 311)
+            pol.dynamics = dyn
+            cfg["env_filter"] = float(np.median(out["step_p1_t1_penalty"]))
+            np.random.seed(78)
+            with RngTap(204) as tap:
+                tr, inf = pol.rollout(torch.from_numpy(obs), 3, True)
+            out.update(actor_seed=311, wsum_actor=gi.checksum(pa), env_filter=cfg["env_filter"], n_steps=len(tap.eps),
+                       num_transitions=inf["num_transitions"])
+            for t, (e, i) in enumerate(zip(tap.eps, tap.idx)):
+                out[f"roll_eps{t}"] = e; out[f"roll_idx{t}"] = i
+            for k, v in tr.items():
+                out["roll_" + k] = v.numpy()
+            print("mopo rollout rows", [e.shape[1] for e in tap.eps], "kept", len(tr["obss"]))
+        print("mopo", tag, "terminated rows:", int(out["step_p1_t1_terminal"].sum()), "/", B)
+        save(f"g18_mopo_{tag}", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g234", "g5", "g6", "g7", "g8", "g9", "g9b", "g11", "g12", "g13", "g14", "g16", "g17", "g18"]
     for w in which:
         globals()[w]()

@@ -76,3 +76,12 @@ def g17_batch(k, cfg, bs, S, A):
     win = lambda rows, n: [x[(k * 13) % (96 - n + 1):][:n].copy() for x in rows]
     parts = [win(src, ns), win(tar, nt), win(fake, nf)]
     return tuple(np.concatenate([p[i] for p in parts], 0) for i in range(5)), ns + nt
+
+
+def mopo_params_for(g, tag):
+    """The weights a g18 fixture was produced with (MOPO ablation), checksum verified."""
+    S, A = int(g["S"]), int(g["A"])
+    p = gi.dyn_params(int(g["seed"]), S, A, mopo=True)
+    p["za_src3.bias"][:, 0, 0] += np.float32(-0.35 if tag == "walker" else -0.3)
+    assert abs(gi.checksum(p) - float(g["wsum"])) <= 1e-9 * abs(float(g["wsum"])), "weight generator drifted from the fixture"
+    return p

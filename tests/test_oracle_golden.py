@@ -50,6 +50,38 @@ def test_g234_dynamics(tag):
     assert 0 < g["step_p1_t1_terminal"].sum() < len(obs)      # fixture exercises both outcomes
 
 
+@pytest.mark.parametrize("tag", ["walker", "ant"])
+def test_g18_mopo_ablation(tag):
+    """config['mopo'] = 1: means = s + MLP_e([s, a]) for both models, then the unchanged step (and a 3-step rollout)."""
+    g = gu.load(f"g18_mopo_{tag}")
+    p = O.to_torch(gu.mopo_params_for(g, tag))
+    obs, act = O.T(g["obs"]), O.T(g["act"])
+    with torch.no_grad():
+        close(O.dyn_forward(p, obs, act, True)[0], g["mean_trg"]); close(O.dyn_forward(p, obs, act, False)[0], g["mean_src"])
+    assert (g["mean_trg"] == g["mean_src"]).all()
+    task = str(g["task"])
+    for up in (1, 0):
+        for ut in (1, 0):
+            k = f"step_p{up}_t{ut}_"
+            with torch.no_grad():
+                st = O.dyn_step(p, obs, act, g[k + "eps"], g[k + "idx"], task, penalty_coef=0.1, use_penalty=bool(up), use_trg=bool(ut))
+            close(st["next_obs"], g[k + "next_obs"]); close(st["reward"], g[k + "reward"])
+            close(st["penalty"], g[k + "penalty"]); close(st["raw_reward"], g[k + "raw_reward"])
+            assert (st["terminal"] == g[k + "terminal"]).all()
+    assert 0 < g["step_p1_t1_terminal"].sum() < len(obs)
+    if tag == "walker":
+        pa, _, _ = gu.policy_params(int(g["actor_seed"]), int(g["S"]), int(g["A"]))
+        n = int(g["n_steps"])
+        cfg = gu.policy_cfg(int(g["S"]), int(g["A"]), env_filter=float(g["env_filter"]))
+        with torch.no_grad():
+            tr, info = O.rollout(O.to_torch(pa), p, g["obs"], 3, [g[f"roll_eps{t}"] for t in range(n)],
+                                 [g[f"roll_idx{t}"] for t in range(n)], task, cfg, penalty_coef=0.1)
+        assert info["num_transitions"] == int(g["num_transitions"])
+        for k in ("obss", "next_obss", "actions", "rewards", "terminals", "penalty"):
+            assert tr[k].shape == g["roll_" + k].shape, k
+            close(tr[k], g["roll_" + k], rtol=2e-5, atol=2e-5)
+
+
 def test_g5_termination():
     g = gu.load("g5_termination")
     tasks = sorted({k.split("::")[0] for k in g if "::" in k})
