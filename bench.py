@@ -98,13 +98,37 @@ def spawn_ranks(args):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
+    # Poll every child: a rank that dies early (bad device, RCCL init failure) would leave rank 0 waiting in a collective
+    # until the RCCL watchdog fires, so on the first non-zero exit the remaining children (ours, by handle) are stopped.
+    import threading
+    out_chunks = []
+    reader = threading.Thread(target=lambda: out_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() is not None and p.returncode != 0:
+                failed = r
+                break
+        time.sleep(0.2)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        print(f"bench.py: rank {failed} exited with code {procs[failed].returncode}; stopped the other ranks", file=sys.stderr)
     rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    out = b"".join(out_chunks)
     for line in out.decode().splitlines():              # only the JSON line (gloo / RCCL may chat on stdout)
         if line.startswith("{"):
             print(line)
     sys.stdout.flush()
-    return max(abs(rc) for rc in rcs)
+    return max(abs(rc) for rc in rcs) if failed is None else (abs(procs[failed].returncode) or 1)
 
 
 # ------------------------------------------------------------------------------------------------ GPU side

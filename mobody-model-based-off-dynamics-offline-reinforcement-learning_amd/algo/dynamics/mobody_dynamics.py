@@ -196,7 +196,11 @@ class MOBODYEnsembleDynamics(object):
         S, A, b, dev = m.obs_dim, m.action_dim, batch_size, m.device
         d = bool(use_trg)
         ws = self._ws_for(b)
-        key = (d, b, data[0].data_ptr(), idx.data_ptr(), idx.shape[1], st["blob"].data_ptr(), ws.data_ptr())
+        # every pointer and scalar the captured launches bake in: a graph replayed after any of them moved (a reloaded model,
+        # a second train() call, a changed learning rate) would read freed memory or the old constant without any error
+        key = (d, b, idx.shape[1], idx.data_ptr(), ws.data_ptr(), self._pre_ctr.data_ptr(), self._pre_acc.data_ptr(),
+               self._pre_loss.data_ptr(), float(self._lr()), float(self.encoder_loss_coef), int(self.seed)) \
+            + tuple(t.data_ptr() for t in data) + tuple(st[k].data_ptr() for k in ("blob", "blob_T", "m", "v"))
         c = self._pre_ctr                                  # [batch index, call, t_main, t_za]: one launch advances all four
         c.copy_(torch.tensor([-1, self._train_calls, st["t_main"], st["t_za"][d]], dtype=torch.int64), non_blocking=False)
         self._pre_acc.zero_()
@@ -331,6 +335,7 @@ class MOBODYEnsembleDynamics(object):
         dev = m.device
         self.src_replay_buffer = src_data
         self.total_steps = 0
+        self._pre_graphs.clear()                          # graphs of an earlier train() call captured that call's tensors
         f = lambda x, c: torch.as_tensor(x, dtype=torch.float32).reshape(len(x), c).to(dev)
         S, A = m.obs_dim, m.action_dim
         src = [f(src_data[0], S), f(src_data[1], A), f(src_data[2], S), f(src_data[3], 1)]

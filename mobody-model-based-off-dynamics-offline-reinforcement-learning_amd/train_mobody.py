@@ -10,9 +10,11 @@ default when gym/d4rl are not importable) fills the replay buffers with syntheti
 transitions and random-initialised networks and skips simulator evaluation; `--synthetic 0` trains on real
 offline datasets without the simulators: `--src_data` (an .npz in d4rl.qlearning_dataset's layout) and `--tar_data` (the
 ODRL target file: .npz of its raw arrays, or the .hdf5 itself when h5py is importable; default: the reference's
-`dataset/<domain>/<env>_<shift>_<quality>.hdf5` path), ingested exactly as train_mobody.py:548-557 does.  `--train_dynamics 1` pre-trains the
-ensemble dynamics on the buffers (MOBODYEnsembleDynamics.train) and saves it under `--dynamics_path` in the
-reference's directory scheme; an existing `dynamics.pth` there is loaded instead when `--train_dynamics 0`.
+`dataset/<domain>/<env>_<shift>_<quality>.hdf5` path), ingested exactly as train_mobody.py:548-557 does.  The ensemble
+dynamics follows the reference's load-or-train branches (`build_dynamics`, train_mobody.py:817-877): load
+`--dynamics_path` / the default `pretrained_dynamics/<env>/srcdatatype-...` tree when present and `--train_dynamics 0`,
+otherwise `MOBODYEnsembleDynamics.train` on the two buffers, then save in the reference's directory scheme.  A random
+"alive" ensemble is kept only under an explicit `--synthetic 1` with nothing to load.
 """
 import argparse
 import json
@@ -179,6 +181,61 @@ def build_config(args, state_dim, action_dim, max_action):
     return config
 
 
+def dynamics_save_path(args, root):
+    """`<root>/<env>/srcdatatype-<src>-tardatatype-<tar>-<shift>` (train_mobody.py:822-823, 843-844)."""
+    return os.path.join(root, args.env, f"srcdatatype-{args.srctype}-tardatatype-{args.tartype}-{args.shift_level}")
+
+
+def build_dynamics(args, dynamics, model, src_rb, tar_rb, writer, task, explicit_synthetic):
+    """The reference's load-or-train logic for the ensemble dynamics (train_mobody.py:817-877), branch for branch:
+
+    * `--dynamics_path P --train_dynamics 0`: load `P/<env>/srcdatatype-...` when that directory exists, otherwise train on
+      the two buffers and save there (:819-840);
+    * otherwise the default tree `pretrained_dynamics/<env>/srcdatatype-...` is tried: loaded when it exists and
+      `--train_dynamics 0` (a failing load falls through to training, :848-864), else the model is trained
+      (`dynamics.train(src_all, trg_all, writer=writer, buffer=[src, tar])`) and saved -- under `--dynamics_path` when
+      one is given, under the default tree when not (:865-877).
+
+    The one addition of this build: with an EXPLICIT `--synthetic 1`, no `--dynamics_path` and nothing in the default tree,
+    `--train_dynamics 0` keeps a random-initialised ensemble whose transition head is shifted into the task's alive box (benchmarks and smoke runs on
+    synthetic buffers; there is nothing to learn from them).  Returns 'loaded' / 'trained' / 'random'."""
+    from mobody_amd import synthetic
+
+    def train_and_save(save_path):
+        if explicit_synthetic:
+            synthetic.alive_dynamics(model, task)          # synthetic buffers only: start inside the alive box
+        dynamics.optim = type("Opt", (), {"param_groups": [{"lr": args.dynamics_lr}]})()
+        dynamics.train(src_rb.sample_all(), tar_rb.sample_all(), writer=writer, buffer=[src_rb, tar_rb],
+                       max_epochs=args.dynamics_max_epochs)
+        if args.dynamics_path is not None:                                     # :831-836, 855-860, 867-872
+            save_path = dynamics_save_path(args, args.dynamics_path)
+        os.makedirs(save_path, exist_ok=True)
+        dynamics.save(save_path)
+        print(f"----------dynamics trained and saved to {save_path}----------")
+        return "trained"
+
+    if args.dynamics_path is not None and args.train_dynamics == 0:            # :819-840
+        save_path = dynamics_save_path(args, args.dynamics_path)
+        if os.path.exists(save_path):
+            dynamics.load(save_path)
+            print("----------pretrained dynamics loaded----------")
+            return "loaded"
+        return train_and_save(save_path)
+    save_path = dynamics_save_path(args, "pretrained_dynamics")                # :842-846
+    if os.path.exists(save_path) and args.train_dynamics == 0:
+        try:
+            dynamics.load(save_path)
+            print("----------pretrained dynamics loaded----------")
+            return "loaded"
+        except Exception:                                                      # the reference's bare `except:` (:851)
+            return train_and_save(save_path)
+    if explicit_synthetic and args.train_dynamics == 0:
+        synthetic.alive_dynamics(model, task)
+        print("--synthetic 1: nothing to load, random-initialised ensemble dynamics (pass --train_dynamics 1 to pre-train it)")
+        return "random"
+    return train_and_save(save_path)
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if "_" in args.env:
@@ -232,33 +289,14 @@ def main(argv=None):
                          reward_relu=args.relu_reward, config=config)
     dynamics = MOBODYEnsembleDynamics(config, model, None, None, terminal_fn, penalty_coef=env_penalty_coef,
                                       rng=args.rng, seed=args.seed + 3)
-    save_dir = None
-    if args.dynamics_path is not None:
-        save_dir = os.path.join(args.dynamics_path, args.env,
-                                f"srcdatatype-{args.srctype}-tardatatype-{args.tartype}-{args.shift_level}")
-    if save_dir is not None and os.path.exists(os.path.join(save_dir, "dynamics.pth")) and args.train_dynamics == 0:
-        dynamics.load(save_dir)                                            # train_mobody.py:821-827, 848-851
-        print("----------pretrained dynamics loaded----------")
-    elif args.train_dynamics == 1:
-        # pre-train on the buffers exactly as the reference does when nothing can be loaded (:817-877):
-        # dynamics.train(src_buffer.sample_all(False), tar_buffer.sample_all(False)), then save under dynamics_path
-        synthetic.alive_dynamics(model, task)
-        dynamics.optim = type("Opt", (), {"param_groups": [{"lr": args.dynamics_lr}]})()
-        dynamics.train(src_rb.sample_all(), tar_rb.sample_all(), writer=None, buffer=[src_rb, tar_rb],
-                       max_epochs=args.dynamics_max_epochs)
-        if save_dir is not None:
-            os.makedirs(save_dir, exist_ok=True)
-            dynamics.save(save_dir)
-    else:
-        synthetic.alive_dynamics(model, task)
-        print("synthetic mode: random-initialised ensemble dynamics (pass --train_dynamics 1 to pre-train it on the buffers)")
+    outdir = f"{args.dir}/{args.policy}/{args.env}-srcdatatype-{args.srctype}-tardatatype-{args.tartype}-{args.shift_level}/r{args.seed}{args.out_dir_remark}"
+    writer = ScalarLog(f"{outdir}/tb/scalars.csv") if args.scalars else None          # train_mobody.py:455-458
+    build_dynamics(args, dynamics, model, src_rb, tar_rb, writer, task, explicit_synthetic=args.synthetic == 1)
     config.update({"dynamics": dynamics})
     policy.dynamics = dynamics
 
-    outdir = f"{args.dir}/{args.policy}/{args.env}-srcdatatype-{args.srctype}-tardatatype-{args.tartype}-{args.shift_level}/r{args.seed}{args.out_dir_remark}"
     if args.save_model:
         os.makedirs(f"{outdir}/models", exist_ok=True)
-    writer = ScalarLog(f"{outdir}/tb/scalars.csv") if args.scalars else None          # train_mobody.py:455-458
     start = time.time()
     for t in range(int(config["max_step"])):
         policy.train(src_rb, tar_rb, config["batch_size"], writer, None)

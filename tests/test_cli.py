@@ -171,3 +171,116 @@ def test_scalar_log_and_dataset_loading_on_the_host(tmp_path):
     args.src_data = None
     with pytest.raises(NotImplementedError):
         tm.load_datasets(args)
+
+
+class _FakeDyn:
+    """Records what build_dynamics asks of the dynamics object (no GPU)."""
+
+    def __init__(self, load_fails=False):
+        self.calls, self.load_fails, self.optim = [], load_fails, None
+
+    def load(self, path):
+        self.calls.append(("load", path))
+        if self.load_fails:
+            raise RuntimeError("corrupt checkpoint")
+
+    def train(self, src, trg, writer=None, buffer=None, max_epochs=None):
+        self.calls.append(("train", writer, max_epochs))
+
+    def save(self, path):
+        assert os.path.isdir(path)
+        self.calls.append(("save", path))
+
+
+class _FakeRb:
+    def sample_all(self):
+        return ()
+
+
+def _bd(tmp_path, monkeypatch, argv, explicit, dyn=None, make=None):
+    """Run build_dynamics in tmp_path (the default tree `pretrained_dynamics/` is relative to the working directory)."""
+    from mobody_amd import synthetic, train_mobody as tm
+    monkeypatch.chdir(tmp_path)
+    shifted = []
+    monkeypatch.setattr(synthetic, "alive_dynamics", lambda model, task: shifted.append(task))
+    args = tm.build_parser().parse_args(["--policy", "MOBODY", "--env", "walker2d-friction", "--shift_level", "2.0"] + argv)
+    if make:
+        os.makedirs(make)
+    dyn = dyn or _FakeDyn()
+    res = tm.build_dynamics(args, dyn, object(), _FakeRb(), _FakeRb(), "W", "walker2d-medium-v2", explicit_synthetic=explicit)
+    return res, dyn.calls, shifted
+
+
+LEAF = "srcdatatype-medium-tardatatype-medium-2.0"
+
+
+def test_build_dynamics_default_flags_train_and_save_under_the_default_tree(tmp_path, monkeypatch):
+    """train_mobody.py:842-877 with --dynamics_path None, --train_dynamics 0 and nothing on disk: train, then save under
+    pretrained_dynamics/<env>/srcdatatype-...; the writer is handed to dynamics.train; no 'alive' shift on real data."""
+    res, calls, shifted = _bd(tmp_path, monkeypatch, [], explicit=False)
+    want = os.path.join("pretrained_dynamics", "walker2d-friction", LEAF)
+    assert res == "trained" and calls == [("train", "W", None), ("save", want)] and shifted == []
+
+
+def test_build_dynamics_loads_the_default_tree_when_present(tmp_path, monkeypatch):
+    want = os.path.join("pretrained_dynamics", "walker2d-friction", LEAF)
+    res, calls, _ = _bd(tmp_path, monkeypatch, [], explicit=False, make=os.path.join(str(tmp_path), want))
+    assert res == "loaded" and calls == [("load", want)]
+    # a failing load falls through to training and saving (the reference's try / except, :848-864)
+    res, calls, _ = _bd(tmp_path, monkeypatch, [], explicit=False, dyn=_FakeDyn(load_fails=True))
+    assert res == "trained" and [c[0] for c in calls] == ["load", "train", "save"]
+    # --train_dynamics 1 ignores what is on disk (:847) and saves under --dynamics_path when one is given (:867-872)
+    res, calls, _ = _bd(tmp_path, monkeypatch, ["--train_dynamics", "1", "--dynamics_path", str(tmp_path / "dp")], explicit=False)
+    assert res == "trained" and calls == [("train", "W", None), ("save", os.path.join(str(tmp_path / "dp"), "walker2d-friction", LEAF))]
+
+
+def test_build_dynamics_with_a_dynamics_path(tmp_path, monkeypatch):
+    """:819-840: --dynamics_path P --train_dynamics 0 loads P/<env>/srcdatatype-... when it exists, else trains and saves there."""
+    p = os.path.join(str(tmp_path / "dp"), "walker2d-friction", LEAF)
+    res, calls, _ = _bd(tmp_path, monkeypatch, ["--dynamics_path", str(tmp_path / "dp"), "--dynamics_max_epochs", "3"], explicit=False)
+    assert res == "trained" and calls == [("train", "W", 3), ("save", p)]
+    res, calls, _ = _bd(tmp_path, monkeypatch, ["--dynamics_path", str(tmp_path / "dp")], explicit=False)
+    assert res == "loaded" and calls == [("load", p)]
+
+
+def test_build_dynamics_random_model_only_under_explicit_synthetic(tmp_path, monkeypatch):
+    res, calls, shifted = _bd(tmp_path, monkeypatch, [], explicit=True)
+    assert res == "random" and calls == [] and shifted == ["walker2d-medium-v2"]
+    res, calls, shifted = _bd(tmp_path, monkeypatch, ["--train_dynamics", "1"], explicit=True)
+    assert res == "trained" and [c[0] for c in calls] == ["train", "save"] and shifted == ["walker2d-medium-v2"]
+
+
+@pytest.mark.gpu
+def test_cli_default_flags_pretrain_into_the_default_tree(tmp_path, monkeypatch, capsys):
+    """The reference's default path end to end on dataset files: no --dynamics_path, --train_dynamics 0, nothing on disk ->
+    the ensemble is pre-trained on the two buffers and saved under pretrained_dynamics/<env>/...; a second run loads it."""
+    import numpy as np
+    import torch
+    from mobody_amd import train_mobody as tm
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(7)
+    S, A, n, m = 17, 6, 2000, 601
+    mu = np.zeros(S, np.float32); mu[0] = 1.25
+    obs = (mu + 0.1 * rng.standard_normal((n, S))).astype(np.float32)
+    np.savez(tmp_path / "src.npz", observations=obs, actions=rng.uniform(-1, 1, (n, A)).astype(np.float32),
+             next_observations=(obs + 0.01 * rng.standard_normal((n, S))).astype(np.float32),
+             rewards=rng.standard_normal(n).astype(np.float32), terminals=np.zeros(n, bool))
+    tobs = (mu + 0.1 * rng.standard_normal((m, S))).astype(np.float32)
+    np.savez(tmp_path / "tar.npz", observations=tobs, actions=rng.uniform(-1, 1, (m, A)).astype(np.float32),
+             rewards=rng.standard_normal((m, 1)).astype(np.float32), terminals=np.zeros(m, bool), timeouts=np.zeros(m, bool))
+    argv = ["--policy", "MOBODY", "--env", "walker2d-friction", "--shift_level", "2.0", "--mode", "3", "--seed", "3",
+            "--synthetic", "0", "--src_data", str(tmp_path / "src.npz"), "--tar_data", str(tmp_path / "tar.npz"),
+            "--penalty_type", "none", "--src_rollout_batch_size", "300", "--trg_rollout_batch_size", "100", "--max_step", "2",
+            "--params", '{"batch_size": 64, "max_step": 2}', "--dir", str(tmp_path / "logs"), "--dynamics_max_epochs", "1"]
+    pol = tm.main(argv)
+    out = capsys.readouterr().out
+    save = tmp_path / "pretrained_dynamics" / "walker2d-friction" / LEAF
+    assert "dynamics trained and saved" in out and sorted(os.listdir(save)) == ["dynamics.pth", "mu.npy", "std.npy"]
+    assert pol.dynamics.total_steps > 0 and pol.total_it == 2
+    rows = [l.split(",")[0] for l in open(tmp_path / "logs" / "MOBODY" / f"walker2d-friction-{LEAF}" / "r3" / "tb" / "scalars.csv")]
+    assert "trg_loss/dynamics_holdout_loss" in rows                       # dynamics.train received the writer (:829)
+    sd = torch.load(save / "dynamics.pth", weights_only=True)
+    pol2 = tm.main(argv)
+    assert "pretrained dynamics loaded" in capsys.readouterr().out
+    sd2 = pol2.dynamics.model.state_dict()
+    assert all(torch.equal(sd[k].to(sd2[k].device), sd2[k]) for k in sd)
