@@ -73,7 +73,7 @@ def wide_flops(S, A, N, Nt):
     return {"k_mlp3_fwd": 2.0 * 65536 * (8 * N + 2 * Nt), "k_mlp3_bwd": 2.0 * 65536 * 5 * N, "k_wgrad": 0.0}
 
 
-NPROD = {"f32": 0, "bf16": 1, "bf16x2": 3, "bf16x3": 6}
+NPROD = {"f32": 0, "bf16": 1, "bf16x2": 3, "bf16x3": 6, "f16x2": 3}
 
 
 def effective_peak(total_flops, wide, mfma):
@@ -325,7 +325,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch_size", type=int, default=None, help="override the config's per-GPU batch size")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--mfma", default="bf16x3", choices=["f32", "bf16x3", "bf16x2", "bf16"],
+    ap.add_argument("--mfma", default="bf16x3", choices=["f32", "f16x2", "bf16x3", "bf16x2", "bf16"],
                     help="MFMA mode of the 256 x 256 forward / backward GEMMs: bf16x3 (default: three-term split, six products, holds the "
                          "fp32 parity tolerances), exact fp32 (the parity-test mode), bf16x2 (~6e-6) or plain bf16 (~3e-3)")
     ap.add_argument("--no_mode_sweep", action="store_true", help="skip the short runs of the other MFMA modes")
@@ -393,7 +393,7 @@ def main():
     # the other MFMA modes, 100 steps each on the same buffers (extra information; the headline is args.mfma)
     sweep = {}
     if not args.no_mode_sweep and world == 1:             # single GPU only: the scaling runs time the headline mode alone
-        for mode in ("f32", "bf16x3", "bf16x2", "bf16"):
+        for mode in ("f32", "f16x2", "bf16x3", "bf16x2", "bf16"):
             if mode == args.mfma:
                 continue
             p2 = build(dev, c, args.graph, mode, buffers=(src, tar))[0]
@@ -462,6 +462,9 @@ def main():
                                      "(~5e-7 of max|out| from the fp32 kernels); holds the fp32 parity tolerances against the reference's "
                                      "golden vectors (tests/test_hip_precision.py; the whole -m gpu suite passes with MOBODY_MFMA=bf16x3); "
                                      "the exact-fp32 step time of the same run is under other_mfma_modes.f32",
+                           "f16x2": "fp32 operands as two fp16 terms (22 significand bits) with exact power-of-two tile scales, three "
+                                    "fp16 MFMAs per fp32 product, fp32 accumulate: fp32-grade; holds the fp32 parity tolerances "
+                                    "against the reference's golden vectors",
                            "bf16x2": "two bf16 terms, three products (~6e-6): throughput mode, not parity grade",
                            "bf16": "plain bf16 MFMA inputs (~3e-3): throughput mode, not parity grade"}[args.mfma],
             "config": {"workload": f"{args.config}: {c['label']} (S={S} A={A}, ensemble 7, rollout_len {c['H']}, N={N} rows per "

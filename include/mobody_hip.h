@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MOBODY_ABI_VERSION 3
+#define MOBODY_ABI_VERSION 4
 #define MOBODY_E_ARG (-1)      /* bad argument (dims, null pointer, unsupported size) */
 #define MOBODY_E_LAUNCH (-2)   /* hipLaunch / runtime error */
 #define MOBODY_E_UNSUPPORTED (-3)
@@ -78,17 +78,24 @@ typedef struct MobodyDynLayout {
  * Parameter blob, per member: W1[Kp1][256] b1[256] W2[256][256] b2[256] W3[256][Np3] b3[Np3]
  * (W stored [in][out], i.e. the transpose of nn.Linear.weight).  The same layout is used for
  * gradients and both Adam moments.  The "T" blob holds the transposes the backward pass
- * streams as MFMA B operands: W3T[Np3][256] W2T[256][256] W1T[256][Np1t] per member, followed by the bf16 planes of
- * W2 and W2^T that the split-precision modes stream (precision 1 "bf16": one plane, 2 "bf16x2": two planes / three
- * products, 3 "bf16x3": three planes / six products; 0 = exact fp32 MFMA, the default and the parity mode). */
+ * streams as MFMA B operands: W3T[Np3][256] W2T[256][256] W1T[256][Np1t] per member, followed by the 16-bit planes of
+ * W2 and W2^T that the split-precision modes stream.  Precision modes (`precision` arguments, MobodyHyper.precision):
+ *   0 "f32"     exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic
+ *   1 "bf16"    one bf16 plane, one product (~3e-3)
+ *   2 "bf16x2"  two bf16 planes, three products (~6e-6)
+ *   3 "bf16x3"  three bf16 planes, six products: fp32-grade
+ *   4 "f16x2"   two fp16 planes (w * 2^8 in the weight planes, per-tile power-of-two scales on the activation side),
+ *               three products: fp32-grade at half the MFMA work of bf16x3
+ * Modes 0-3 share one plane format (three bf16 planes); mode 4 keeps its two fp16 planes in the first two plane slots.
+ * Whoever writes planes (mobody_mlp_transpose, the Adam entry points, mobody_dyn_planes) is told the mode. */
 typedef struct MobodyMlpLayout {
   int32_t in_dim, out_dim, members, Kp1, Np3, Np1t;
   int64_t w1, b1, w2, b2, w3, b3;   /* float offsets inside one member */
   int64_t member_floats, total_floats;
   int64_t w3t, w2t, w1t;            /* float offsets inside one member of the T blob */
   int64_t t_member_floats, t_total_floats;
-  int64_t w2p, w2tp;                /* float offsets (inside one member of the T blob) of the bf16 planes of W2 and W2^T:
-                                       [3 planes][32][256][8] bf16 each, x = x0 + x1 + x2 (split-precision modes) */
+  int64_t w2p, w2tp;                /* float offsets (inside one member of the T blob) of the planes of W2 and W2^T:
+                                       [3 planes][32][256][8] 16-bit each, x = x0 + x1 (+ x2) (split-precision modes) */
 } MobodyMlpLayout;
 
 const char* mobody_last_error(void);
@@ -114,11 +121,11 @@ int mobody_rng_index(uint32_t seed, uint32_t stream_id, uint32_t call, int64_t n
 int mobody_dyn_forward(const float* dyn_blob, const float* dyn_planes, int precision, int S, int A, const float* obs,
                        const float* act, int64_t B, int use_trg, float* mean, void* stream);
 /* dyn_planes / precision (here and in mobody_dyn_step / mobody_rollout): 0 = exact fp32 MFMA (planes may be NULL);
- * 1 bf16, 2 bf16x2, 3 bf16x3 = the three 256 x 256 layers of every member (zs2, transition2, reward_model2) on the
- * split-precision bf16 core, streaming the planes mobody_dyn_planes built from the blob
- * (mobody_dyn_planes_floats() floats: [3 layers][7 members][3 planes][65536] bf16). */
+ * 1 bf16, 2 bf16x2, 3 bf16x3, 4 f16x2 = the three 256 x 256 layers of every member (zs2, transition2, reward_model2) on the
+ * split-precision core, streaming the planes mobody_dyn_planes built from the blob FOR THAT MODE
+ * (mobody_dyn_planes_floats() floats: [3 layers][7 members][3 planes][65536] 16-bit). */
 int64_t mobody_dyn_planes_floats(void);
-int mobody_dyn_planes(const float* dyn_blob, int S, int A, float* planes, void* stream);
+int mobody_dyn_planes(const float* dyn_blob, int S, int A, float* planes, int precision, void* stream);
 
 /* floats of scratch mobody_dyn_step needs for a batch of B rows */
 int64_t mobody_dyn_step_workspace(int S, int A, int64_t B);
@@ -207,8 +214,8 @@ int mobody_counter_add(int64_t* counter, int n, int64_t inc, void* stream);
 int mobody_mlp3_forward(const float* blob, const float* blob_T, int precision, int in_dim, int out_dim, int members,
                         const float* src0, int n0, const float* src1, int n1, int64_t rows, int out_mode,
                         float max_action, float* out, float* save_x, float* save_h1, float* save_h2, void* stream);
-/* blob_T / precision: 0 = exact fp32 MFMA (blob_T may be NULL); 1..3 = the split-precision modes, which stream W2's
- * bf16 planes from the T blob (mobody_mlp_transpose builds them, the Adam kernels keep them current). */
+/* blob_T / precision: 0 = exact fp32 MFMA (blob_T may be NULL); 1..4 = the split-precision modes, which stream W2's
+ * planes from the T blob (mobody_mlp_transpose builds them, the Adam kernels keep them current -- both for the SAME mode). */
 
 /* ---- replay gather / ring append ------------------------------------------------------- */
 /* Concatenate rows idx_k of up to three buffers (src | tar | fake order, mobody.py:525-529)
@@ -250,8 +257,9 @@ typedef struct MobodyTrainDims {
 typedef struct MobodyHyper {
   float gamma, tau, max_action, weight, bc_coef;
   int32_t q_weighted, scale_q;
-  int32_t precision;   /* MFMA mode of the 256 x 256 GEMMs of the forward AND backward passes (weight gradients stay fp32):
-                          0 exact fp32 (default, parity), 1 bf16, 2 bf16x2, 3 bf16x3 */
+  int32_t precision;   /* MFMA mode of the 256 x 256 GEMMs of the forward and backward passes and of the 256 x 256
+                          weight-gradient job: 0 exact fp32 (the reference's arithmetic), 1 bf16, 2 bf16x2, 3 bf16x3, 4 f16x2;
+                          the update entry points also write the nets' W2 planes in this mode's format */
 } MobodyHyper;
 
 /* floats of scratch the training calls need.  The SAME workspace has to be handed to mobody_actor_forward and the
@@ -317,14 +325,15 @@ int mobody_value_loss_grad(const float* qt, const float* v, int64_t N, int64_t N
  * gradient first (1/world for an all-reduced SUM). */
 int mobody_adam_polyak(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad, float* m,
                        float* v, float* target, float* target_T, int64_t t, float lr, float tau, float grad_scale,
-                       void* stream);
-/* target_T (nullable): T blob of the target net, whose W2 planes then follow the Polyak update (split-precision modes). */
+                       int precision, void* stream);
+/* target_T (nullable): T blob of the target net, whose W2 planes then follow the Polyak update (split-precision modes).
+ * precision: format of the W2 planes written into blob_T / target_T (the mode the nets are evaluated in). */
 
 /* Same, with the 1-based step count read from DEVICE memory (t_dev[0]) so that a captured HIP graph advances
  * without new kernel arguments (bias corrections are formed in double on the device). */
 int mobody_adam_polyak_dev(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad,
                            float* m, float* v, float* target, float* target_T, const int64_t* t_dev, float lr, float tau,
-                           float grad_scale, void* stream);
+                           float grad_scale, int precision, void* stream);
 
 /* PAR reward shaping: reward[i] -= coef * mean_d (next_state_true[i][d] - next_state_model[i][d])^2  (mobody.py:428-434) */
 int mobody_par_penalty(const float* next_state_true, const float* next_state_model, float* reward, float coef,
@@ -413,8 +422,10 @@ int64_t mobody_dyn_validate_workspace(int S, int A, int64_t B);
 int mobody_dyn_validate(const float* dyn_blob, int S, int A, const float* obs, const float* act, const float* next_obs,
                         const float* rew, int64_t B, int use_trg, float* out, float* workspace, void* stream);
 
-/* (Re)build the transposed blob from a parameter blob (after loading a checkpoint). */
-int mobody_mlp_transpose(int in_dim, int out_dim, int members, const float* blob, float* blob_T, void* stream);
+/* (Re)build the transposed blob from a parameter blob (after loading a checkpoint); `precision` selects the format of
+ * the W2 / W2^T planes it writes (the mode the net will be evaluated in). */
+int mobody_mlp_transpose(int in_dim, int out_dim, int members, const float* blob, float* blob_T, int precision,
+                         void* stream);
 
 #ifdef __cplusplus
 }

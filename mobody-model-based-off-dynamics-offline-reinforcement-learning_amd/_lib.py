@@ -54,7 +54,7 @@ class MobodyHyper(C.Structure):
                 ("q_weighted", i32), ("scale_q", i32), ("precision", i32)]
 
 
-PRECISIONS = {"f32": 0, "bf16": 1, "bf16x2": 2, "bf16x3": 3}
+PRECISIONS = {"f32": 0, "bf16": 1, "bf16x2": 2, "bf16x3": 3, "f16x2": 4}
 
 
 TERM_IDS = {"never": 0, "halfcheetah": 1, "hopper": 2, "ant": 3, "walker2d": 4, "humanoid": 5, "pen": 6}
@@ -71,7 +71,7 @@ PROTOTYPES = {
     "mobody_rng_index": (C.c_int, [u32, u32, u32, i64, u32, vp, vp]),
     "mobody_dyn_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, i64, C.c_int, vp, vp]),
     "mobody_dyn_planes_floats": (i64, []),
-    "mobody_dyn_planes": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    "mobody_dyn_planes": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "mobody_dyn_step_workspace": (i64, [C.c_int, C.c_int, i64]),
     "mobody_dyn_step": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, i64, vp, vp, vp, C.POINTER(i32), C.c_int,
                                   u32, u32, f32, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -106,15 +106,15 @@ PROTOTYPES = {
                                        C.c_int, vp]),
     "mobody_actor_backward": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp,
                                         vp, vp, vp, vp, vp, vp]),
-    "mobody_adam_polyak": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, vp]),
-    "mobody_adam_polyak_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp]),
+    "mobody_adam_polyak": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, C.c_int, vp]),
+    "mobody_adam_polyak_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, C.c_int, vp]),
     "mobody_par_penalty": (C.c_int, [vp, vp, vp, f32, i64, C.c_int, vp]),
     "mobody_mlp3_backward_workspace": (i64, [C.c_int, C.c_int, C.c_int, i64]),
     "mobody_mlp3_backward": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, i64, vp, vp, vp]),
     "mobody_dara_inputs": (C.c_int, [vp, vp, vp, i64, C.c_int, C.c_int, f32, vp, vp, u32, u32, vp, vp, vp]),
     "mobody_dara_loss_grad": (C.c_int, [vp, vp, vp, i64, i64, vp, vp, vp, vp, vp]),
     "mobody_dara_penalty": (C.c_int, [vp, vp, i64, f32, vp, vp, vp]),
-    "mobody_mlp_transpose": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "mobody_mlp_transpose": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "mobody_pretrain_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(MobodyPretrainLayout)]),
     "mobody_pretrain_transpose": (C.c_int, [C.c_int, C.c_int, vp, vp, vp]),
     "mobody_pretrain_workspace": (i64, [C.c_int, C.c_int, i64]),
@@ -147,7 +147,7 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.mobody_abi_version() != 3:
+    if lib.mobody_abi_version() != 4:
         raise ImportError("libmobody_hip.so ABI version mismatch")
     _lib = lib
     return lib

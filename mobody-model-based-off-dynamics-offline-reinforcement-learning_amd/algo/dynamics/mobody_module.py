@@ -200,18 +200,22 @@ class MOBODYModule(object):
                         for li, k in ((0, 1), (2, 2), (4, 3))} | {f"network.{li}.bias": self._p[f"za_src{k}.bias"][e, 0]
                                                                    for li, k in ((0, 1), (2, 2), (4, 3))} for e in range(7)]
             blob = packing.pack_mlp(members, S + A, S, self.device)
-            self._mopo = (blob, ops.mlp_transpose(blob, S + A, S, 7))
+            self._mopo = (blob, ops.mlp_transpose(blob, S + A, S, 7, precision=self._prec()))
         return self._mopo
 
+    def _prec(self):
+        return ops.prec_id(self.config.get("mfma", ops.default_mfma()))
+
     def planes(self):
-        """bf16 planes of the three 256 x 256 layers (split-precision modes), rebuilt with the packed blob."""
+        """16-bit planes of the three 256 x 256 layers in the configured split-precision mode's format, rebuilt with the
+        packed blob."""
         blob = self.packed()
         if self._planes is None:
-            self._planes = ops.dyn_planes(blob, self.obs_dim, self.action_dim)
+            self._planes = ops.dyn_planes(blob, self.obs_dim, self.action_dim, precision=self._prec() or 3)
         return self._planes
 
     def _fwd(self, state, action, use_trg):
-        prec = ops.prec_id(self.config.get("mfma", ops.default_mfma()))
+        prec = self._prec()
         if self.mopo:                                   # s + f(s, a): forward_trg == forward_src (:264-266)
             s = torch.as_tensor(state, dtype=torch.float32).to(self.device).contiguous()
             a = torch.as_tensor(action, dtype=torch.float32).to(self.device).reshape(-1, self.action_dim).contiguous()

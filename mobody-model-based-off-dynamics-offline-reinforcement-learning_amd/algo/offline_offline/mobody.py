@@ -29,9 +29,10 @@ REFRESH_FROM_SRC_TAR = 100                # target init states of the rollout_fr
 class _PackedNet(object):
     """nn.Module-like handle on a packed 3-layer MLP (actor: 1 member, twin-Q: 2 members)."""
 
-    def __init__(self, in_dim, out_dim, members, prefixes, device, out_mode=0, max_action=1.0, init=True):
+    def __init__(self, in_dim, out_dim, members, prefixes, device, out_mode=0, max_action=1.0, init=True, precision=0):
         self.in_dim, self.out_dim, self.members, self.prefixes = in_dim, out_dim, members, prefixes
         self.device, self.out_mode, self.max_action = device, out_mode, float(max_action)
+        self.precision = int(precision)               # MFMA mode the net is evaluated in = format of the W2 planes in blob_T
         self.layout = _lib.mlp_layout(in_dim, out_dim, members)
         if init:                                      # nn.Linear default init (kaiming_uniform a=sqrt(5))
             sd = {}
@@ -48,10 +49,10 @@ class _PackedNet(object):
                                   prefixes=list(self.prefixes))
         if getattr(self, "blob", None) is None:
             self.blob = packed
-            self.blob_T = ops.mlp_transpose(self.blob, self.in_dim, self.out_dim, self.members)
+            self.blob_T = ops.mlp_transpose(self.blob, self.in_dim, self.out_dim, self.members, precision=self.precision)
         else:                                         # in place: captured graphs and Adam hold these pointers
             self.blob.copy_(packed)
-            ops.mlp_transpose(self.blob, self.in_dim, self.out_dim, self.members, out=self.blob_T)
+            ops.mlp_transpose(self.blob, self.in_dim, self.out_dim, self.members, out=self.blob_T, precision=self.precision)
         self.version = getattr(self, "version", 0) + 1
 
     def state_dict(self):
@@ -65,7 +66,7 @@ class _PackedNet(object):
 
     def clone(self):
         c = _PackedNet(self.in_dim, self.out_dim, self.members, self.prefixes, self.device, self.out_mode,
-                       self.max_action, init=False)
+                       self.max_action, init=False, precision=self.precision)
         c.blob, c.blob_T = self.blob.clone(), self.blob_T.clone()
         return c
 
@@ -79,7 +80,7 @@ class _PackedNet(object):
     def __call__(self, x, x2=None):
         x = torch.as_tensor(x, dtype=torch.float32).to(self.device)
         o = ops.mlp3_forward(self.blob, self.in_dim, self.out_dim, self.members, x, x2, self.out_mode, self.max_action,
-                             blob_T=self.blob_T, precision=getattr(self, "precision", 0))
+                             blob_T=self.blob_T, precision=self.precision)
         return o[0] if self.members == 1 else tuple(o[m] for m in range(self.members))
 
 
@@ -96,14 +97,14 @@ class _Adam(object):
         n = self.net
         ops.adam_polyak(n.in_dim, n.out_dim, n.members, n.blob, n.blob_T, self.grad, self.m, self.v,
                         None if target is None else target.blob, self.t, self.lr, tau, grad_scale,
-                        target_T=None if target is None else target.blob_T)
+                        target_T=None if target is None else target.blob_T, precision=n.precision)
 
     def step_dev(self, t_dev, target=None, tau=-1.0):
         """Graph-capturable step: the 1-based step count is read from the device word `t_dev` (already advanced)."""
         n = self.net
         ops.adam_polyak_dev(n.in_dim, n.out_dim, n.members, n.blob, n.blob_T, self.grad, self.m, self.v,
                             None if target is None else target.blob, t_dev, self.lr, tau, 1.0,
-                            target_T=None if target is None else target.blob_T)
+                            target_T=None if target is None else target.blob_T, precision=n.precision)
 
     def _unpack(self, blob):
         n = self.net
@@ -186,22 +187,22 @@ class MOBODY(object):
         self.penalty_type = config["penalty_type"]
         S, A = int(config["state_dim"]), int(config["action_dim"])
         self.S, self.A = S, A
-        # MFMA mode of the 256 x 256 forward layers: 'f32' exact (default, the parity mode) | 'bf16x3' | 'bf16x2' | 'bf16'
+        # MFMA mode of the 256 x 256 layers: 'f32' exact | 'f16x2' | 'bf16x3' (both fp32-grade) | 'bf16x2' | 'bf16'
         self.mfma = str(config.get("mfma", ops.default_mfma()))
         self.precision = ops.prec_id(self.mfma)
         self.rng = config.get("rng", "numpy")               # 'numpy' = reference index/elite streams; 'device' = Philox
         self.seed = int(config.get("seed", 0))
         self.fake_replay_buffer = utils.ReplayBuffer(S, A, self.device, rng=self.rng, seed=self.seed + 17)
         self.total_it = 0
-        self.q_funcs = _PackedNet(S + A, 1, 2, ("network1.", "network2."), self.device)
+        self.q_funcs = _PackedNet(S + A, 1, 2, ("network1.", "network2."), self.device, precision=self.precision)
         self.target_q_funcs = self.q_funcs.clone().eval()                         # deepcopy, mobody.py:116
-        self.policy = _PackedNet(S, A, 1, ("network.",), self.device, out_mode=1, max_action=config["max_action"])
+        self.policy = _PackedNet(S, A, 1, ("network.",), self.device, out_mode=1, max_action=config["max_action"],
+                                 precision=self.precision)                         # select_action / rollouts at the configured precision
         self.v_func = _PackedNet(S, 1, 1, ("network.",), self.device)                # ValueFunc, mobody.py:50-57,121
         self.v_optimizer = _Adam(self.v_func, config["critic_lr"])
         self._v_ws = None
         self.q_optimizer = _Adam(self.q_funcs, config["critic_lr"])
         self.policy_optimizer = _Adam(self.policy, config["actor_lr"])
-        self.policy.precision = self.precision             # select_action / rollouts at the configured precision
         self.classifier = _Classifier(S, A, self.device, config["gaussian_noise_std"], config["actor_lr"])
         self.dynamics = None
         self._ws, self._ws_key = None, None

@@ -28,7 +28,7 @@ struct DynFwdArgs {
   float* mean;        // [E][B][S]
   long long B;
   int use_trg;
-  const unsigned short* planes;   // split-precision modes: bf16 planes of zs2 | transition2 | reward_model2 (dyn_planes_off)
+  const unsigned short* planes;   // split-precision modes: 16-bit planes of zs2 | transition2 | reward_model2 (dyn_planes_off)
 };
 
 // bf16 planes of the three 256 x 256 ensemble layers: [layer 0..2 = zs2, transition2, reward_model2][member][3 planes][65536]
@@ -37,14 +37,15 @@ __host__ __device__ inline long long dyn_planes_off(int layer, int member) { ret
 
 // NT3: 16-column tiles of the transition head handled by the K-split narrow layer (Np == 16*NT3: 1, 2, 3 or 7), 0 = any width
 // (row-split narrow_layer: half of the waves idle on a 32-row tile).
-// NPL: 0 = exact fp32 MFMA; 1..3 = the two 256 x 256 layers (zs2, transition2) on the split-precision bf16 core.
-template <int MT, int NT3, int NPL>
+// PM: 0 = exact fp32 MFMA; 1..4 = the two 256 x 256 layers (zs2, transition2) on the split-precision core (tile_bf.h).
+template <int MT, int NT3, int PM>
 __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   constexpr int TB = 32 * MT;
-  __bf16* Ps = reinterpret_cast<__bf16*>(Xs);
-  constexpr int NPLX = NPL > 0 ? NPL : 1;
-  BfRing<NPLX> bring;
+  constexpr int PMX = PM > 0 ? PM : 1;
+  char* Ps = reinterpret_cast<char*>(Xs);
+  float* scr = reinterpret_cast<float*>(Ps + split_scr_offset<PMX, TB>());
+  BfRing<PMX> bring;
   const int e = blockIdx.y;
   const long long row0 = (long long)blockIdx.x * TB;
   const int rows_here = (int)min((long long)TB, a.B - row0);
@@ -60,11 +61,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   tile_load(Xs, 0, a.obs + row0 * S, S, S, 0, rows_here, TB);
   tile_zero_cols(Xs, S, a.L.layer[MOBODY_DL_ZS1].Kp, TB);
   lds_barrier();
-  if constexpr (NPL > 0) {
-    const bf16x8* pz = reinterpret_cast<const bf16x8*>(a.planes + dyn_planes_off(0, e));
-    wide_layer_to_planes<ACT_SWISH, MT, NPLX>(Xs, Ps, TB, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, ring,
-                                              NoExtra{}, [&] { bf_prefetch<NPLX>(pz, bring); }, nullptr, false, 0);
-    bf_layer<ACT_SWISH, MT, NPLX>(Xs, Ps, TB, pz, Bp(MOBODY_DL_ZS2), bring, NoExtra{}, [] {}, nullptr, false, 0);
+  if constexpr (PM > 0) {
+    const s16x8* pz = reinterpret_cast<const s16x8*>(a.planes + dyn_planes_off(0, e));
+    const int ez = wide_layer_to_planes<ACT_SWISH, MT, PMX, TB>(Xs, Ps, scr, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1),
+                                                                a.L.layer[MOBODY_DL_ZS1].Kp, ring, NoExtra{},
+                                                                [&] { bf_prefetch<PMX>(pz, bring); }, nullptr, false, 0);
+    bf_layer<ACT_SWISH, MT, PMX, TB>(Xs, Ps, ez, pz, Bp(MOBODY_DL_ZS2), bring, NoExtra{}, [] {}, nullptr, false, 0);
   } else {
     wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, ring, NoExtra{},
                               [&] { wide_prefetch(Wp(MOBODY_DL_ZS2), HID, ring); });
@@ -112,10 +114,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
 
   // ---- transition decoder   (encode_transition :287-293) ----
   wide_prefetch(Wp(MOBODY_DL_TR1), 16, ring);
-  const bf16x8* pt = NPL > 0 ? reinterpret_cast<const bf16x8*>(a.planes + dyn_planes_off(1, e)) : nullptr;
-  if constexpr (NPL > 0)
-    wide_layer_to_planes<ACT_SWISH, MT, NPLX>(Xs, Ps, TB, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, ring, NoExtra{},
-                                              [&] { bf_prefetch<NPLX>(pt, bring); }, nullptr, false, 0);
+  const s16x8* pt = PM > 0 ? reinterpret_cast<const s16x8*>(a.planes + dyn_planes_off(1, e)) : nullptr;
+  int et = 0;
+  if constexpr (PM > 0)
+    et = wide_layer_to_planes<ACT_SWISH, MT, PMX, TB>(Xs, Ps, scr, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, ring, NoExtra{},
+                                                      [&] { bf_prefetch<PMX>(pt, bring); }, nullptr, false, 0);
   else
     wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, ring, NoExtra{},
                               [&] { wide_prefetch(Wp(MOBODY_DL_TR2), HID, ring); });
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   float* mean = a.mean + ((long long)e * a.B + row0) * S;
   // transition2 at the requested precision; `between` runs after its last MFMA (the output layer's early requests)
   auto layer_tr2 = [&](auto&& between) {
-    if constexpr (NPL > 0) bf_layer<ACT_SWISH, MT, NPLX>(Xs, Ps, TB, pt, Bp(MOBODY_DL_TR2), bring, NoExtra{}, between, nullptr, false, 0);
+    if constexpr (PM > 0) bf_layer<ACT_SWISH, MT, PMX, TB>(Xs, Ps, et, pt, Bp(MOBODY_DL_TR2), bring, NoExtra{}, between, nullptr, false, 0);
     else wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, ring, NoExtra{}, between);
   };
   if constexpr (NT3 > 0) {
@@ -279,8 +282,7 @@ __global__ __launch_bounds__(256) void k_dyn_finalize(DynFinalArgs a) {
 
 template <int MT, int NT3, int NPL>
 static int launch_dyn_fwd_t(const DynFwdArgs& a, hipStream_t st) {
-  constexpr size_t f32b = (size_t)32 * MT * LDX * sizeof(float), plb = (size_t)NPL * 32 * MT * LDP * sizeof(__bf16);
-  constexpr size_t lds = f32b > plb ? f32b : plb;
+  constexpr size_t lds = split_lds_bytes<(NPL > 0 ? NPL : 1), 32 * MT>();
   static bool once = false;
   if (!once) {
     int rc = allow_big_lds(k_dyn_fwd<MT, NT3, NPL>, lds);
@@ -307,16 +309,18 @@ static int launch_dyn_fwd(const float* blob, const MobodyDynLayout& L, const flo
   const int np = L.layer[MOBODY_DL_TR3].Np;
   const int nt3 = np == 16 ? 1 : np == 32 ? 2 : np == 48 ? 3 : np == 112 ? 7 : 0;      // walker/hopper/cheetah, pen, ant heads; else generic
   if (prec == 0) return forced == 32 ? launch_dyn_fwd_nt<1, 0>(a, nt3, st) : launch_dyn_fwd_nt<2, 0>(a, nt3, st);
-  // split-precision modes: the planes of a 64-row tile are 34 / 68 / 101 KB for 1 / 2 / 3 terms -> the three-term mode
-  // runs 32-row tiles (51 KB, three workgroups per CU)
-  const bool tall = forced == 64 || (forced != 32 && prec <= 2);
+  // split-precision modes: the planes of a 64-row tile are 32 / 64 / 96 KB for 1 / 2 / 3 terms -> the three-term mode
+  // runs 32-row tiles (48 KB, three workgroups per CU)
+  const bool tall = forced == 64 || (forced != 32 && prec != 3);
   if (prec == 1) return tall ? launch_dyn_fwd_nt<2, 1>(a, nt3, st) : launch_dyn_fwd_nt<1, 1>(a, nt3, st);
   if (prec == 2) return tall ? launch_dyn_fwd_nt<2, 2>(a, nt3, st) : launch_dyn_fwd_nt<1, 2>(a, nt3, st);
+  if (prec == 4) return tall ? launch_dyn_fwd_nt<2, 4>(a, nt3, st) : launch_dyn_fwd_nt<1, 4>(a, nt3, st);
   return tall ? launch_dyn_fwd_nt<2, 3>(a, nt3, st) : launch_dyn_fwd_nt<1, 3>(a, nt3, st);
 }
 
-// zs2 / transition2 / reward_model2 of every member -> their three bf16 planes
-__global__ __launch_bounds__(256) void k_dyn_planes(const float* blob, MobodyDynLayout L, __bf16* planes) {
+// zs2 / transition2 / reward_model2 of every member -> their three bf16 planes (precision 0-3) or two fp16 planes of
+// w * 2^F16_WSHIFT (precision 4)
+__global__ __launch_bounds__(256) void k_dyn_planes(const float* blob, MobodyDynLayout L, short* planes, int precision) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= 3LL * NENS * HID * HID) return;
   const int layer = (int)(gid / ((long long)NENS * HID * HID));
@@ -324,11 +328,18 @@ __global__ __launch_bounds__(256) void k_dyn_planes(const float* blob, MobodyDyn
   const int e = (int)(rem / (HID * HID)), el = (int)(rem % (HID * HID)), k = el / HID, n = el % HID;
   const int li = layer == 0 ? MOBODY_DL_ZS2 : layer == 1 ? MOBODY_DL_TR2 : MOBODY_DL_RW2;
   const float w = blob[L.layer[li].w_off + (long long)e * HID * HID + wide_idx(k, n)];
-  __bf16 t[3];
-  bf_split<3>(w, t);
-  __bf16* pl = planes + dyn_planes_off(layer, e);
+  short* pl = planes + dyn_planes_off(layer, e);
+  if (precision == 4) {
+    short t[2];
+    split_terms<4>(w * exp2i(F16_WSHIFT), t);
 #pragma unroll
-  for (int p = 0; p < 3; ++p) pl[bf_plane_idx(p, k, n)] = t[p];
+    for (int p = 0; p < 2; ++p) pl[bf_plane_idx(p, k, n)] = t[p];
+  } else {
+    short t[3];
+    split_terms<3>(w, t);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pl[bf_plane_idx(p, k, n)] = t[p];
+  }
 }
 
 }  // namespace mobody
@@ -337,19 +348,20 @@ using namespace mobody;
 
 extern "C" int64_t mobody_dyn_planes_floats(void) { return 3LL * NENS * DYN_PLANE_MEMBER / 2; }
 
-extern "C" int mobody_dyn_planes(const float* dyn_blob, int S, int A, float* planes, void* stream) {
+extern "C" int mobody_dyn_planes(const float* dyn_blob, int S, int A, float* planes, int precision, void* stream) {
   MobodyDynLayout L;
   int rc = mobody_dyn_layout(S, A, &L);
   if (rc) return rc;
   MB_REQUIRE(dyn_blob && planes, "mobody_dyn_planes: null pointer");
+  MB_REQUIRE(precision >= 0 && precision <= 4, "mobody_dyn_planes: precision must be 0..4");
   hipLaunchKernelGGL(k_dyn_planes, dim3((unsigned)cdiv(3LL * NENS * HID * HID, 256)), dim3(256), 0, as_stream(stream), dyn_blob, L,
-                     reinterpret_cast<__bf16*>(planes));
+                     reinterpret_cast<short*>(planes), precision);
   MB_LAUNCH_OK("k_dyn_planes");
   return 0;
 }
 
 static int check_dyn_prec(const char* who, int precision, const float* planes) {
-  MB_REQUIRE(precision >= 0 && precision <= 3, "%s: precision must be 0 (f32), 1 (bf16), 2 (bf16x2) or 3 (bf16x3)", who);
+  MB_REQUIRE(precision >= 0 && precision <= 4, "%s: precision must be 0 (f32), 1 (bf16), 2 (bf16x2), 3 (bf16x3) or 4 (f16x2)", who);
   MB_REQUIRE(precision == 0 || planes, "%s: the split-precision modes need the plane blob (mobody_dyn_planes)", who);
   return 0;
 }

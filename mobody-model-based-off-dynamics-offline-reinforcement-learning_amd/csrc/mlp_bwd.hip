@@ -18,27 +18,23 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include "layers.h"
-#include "tile_bf.h"
+#include "layers_bf.h"
 #include "train.h"
 
 namespace mobody {
 
-// Masked epilogue of a backward wide layer: dz = acc * [h > 0] -> LDS image (+ optional global copy) and the
-// per-column sums of the tile (bias gradient).  The 64 mask values of a lane (saved forward activation h at the
-// lane's accumulator positions) are fetched first with UNCONDITIONAL loads from clamped rows -- a
-// `cond ? load : 0` select makes hipcc branch around every load and drain vmcnt(0) after it (64 serialized HBM
-// round trips per layer, measured 60 % SQ_WAIT_ANY) -- so all 64 are in flight together and cost one round trip.
-// (Holding them across the GEMM instead was tried: 256 VGPRs + 62 spills, slower.)
-// Lanes < 32 end up with the 64-row sums of columns 64w + 32nt + (lane&31), nt = 0,1.
+// Masked epilogue of a backward wide layer, in two parts around the barrier that separates the GEMM's LDS reads from the
+// epilogue's LDS writes.
+//
+// wide_mask_apply (before the barrier, registers only): acc <- dz = (acc * prescale) * [h > 0].  The mask values of a lane
+// are fetched with UNCONDITIONAL loads from clamped rows -- a `cond ? load : 0` select makes hipcc branch around every
+// load and drain vmcnt(0) after it (64 serialized HBM round trips per layer, measured 60 % SQ_WAIT_ANY) -- so all of them
+// are in flight together and cost one round trip.  Returns the lane's largest |dz| (the f16 mode's tile scale).
 // MASK: 0 = ReLU mask from the saved activations (h > 0), 1 = ReLU mask from the forward's sign words,
 //       2 = Swish: multiply by the saved derivative d = dy/dz (h points at save_d of the forward, mobody_module.py:9-15).
-// NPL > 0: the masked gradient goes to NPL bf16 planes in LDS (the next GEMM runs on the split-precision core) instead of
-// the fp32 image; the global copy (the weight-gradient operand) and the column sums stay fp32.
-template <int MT, int MASK, int NPL = 0>
-__device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], float* Xs, const float* __restrict__ h,
-                                                       const uint32_t* __restrict__ bits, float* gdst, int rows_here,
-                                                       float (&cs)[2]) {
+template <int MT, int MASK>
+__device__ __forceinline__ float wide_mask_apply(f32x16 (&acc)[MT][2], const float* __restrict__ h,
+                                                 const uint32_t* __restrict__ bits, int rows_here, float prescale) {
   const int lane = lane_id(), w = wave_id();
   const int i = lane & 31, hh = lane >> 5;
   constexpr bool BITS = MASK == 1;
@@ -61,8 +57,8 @@ __device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], flo
         hv[mt][1][r] = hp[row * HID + 32];
       }
   }
-  cs[0] = cs[1] = 0.f;
-  // full tile (wave uniform): no per-element row guard (v_cmp + exec save/restore around each of the 32 stores)
+  float mx = 0.f;
+  // full tile (wave uniform): no per-element row guard
   auto sweep = [&](auto guarded) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -71,28 +67,62 @@ __device__ __forceinline__ void wide_mask_store_colsum(f32x16 (&acc)[MT][2], flo
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rb = (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const int row = 32 * mt + rb;
-          const int col = 64 * w + 32 * nt + i;
-          const bool valid = !decltype(guarded)::value || row < rows_here;
+          const bool valid = !decltype(guarded)::value || 32 * mt + rb < rows_here;
+          const float a = acc[mt][nt][r] * prescale;
           float dz;
           if constexpr (MASK == 2) {
-            dz = valid ? acc[mt][nt][r] * hv[mt][nt][r] : 0.f;
+            dz = valid ? a * hv[mt][nt][r] : 0.f;
           } else {
             bool on;
             if constexpr (BITS) on = (mw[mt][nt] >> rb) & 1u;
             else on = hv[mt][nt][r] > 0.f;
-            dz = (on && valid) ? acc[mt][nt][r] : 0.f;
+            dz = (on && valid) ? a : 0.f;
           }
-          if constexpr (NPL > 0) {
-            __bf16 t[NPL];
-            bf_split<NPL>(dz, t);
-            __bf16* Ps = reinterpret_cast<__bf16*>(Xs);
+          acc[mt][nt][r] = dz;
+          mx = fmaxf(mx, fabsf(dz));
+        }
+  };
+  if (rows_here == 32 * MT) sweep(std::false_type{});
+  else sweep(std::true_type{});
+  return mx;
+}
+
+// wide_store_colsum (after the barrier): dz -> LDS (the fp32 image, or -- PM > 0 -- the 16-bit planes the next GEMM
+// contracts on the split-precision core, scaled by 2^e in the f16 mode), optional global copy (the weight-gradient operand,
+// always fp32) and the per-column sums of the tile (bias gradient).  Lanes < 32 end up with the sums of columns
+// 64w + 32nt + (lane&31), nt = 0,1.
+template <int MT, int PM>
+__device__ __forceinline__ void wide_store_colsum(f32x16 (&acc)[MT][2], float* Xs, float* gdst, int rows_here, int e,
+                                                  float (&cs)[2]) {
+  const int lane = lane_id(), w = wave_id();
+  const int i = lane & 31, hh = lane >> 5;
+  cs[0] = cs[1] = 0.f;
+  if constexpr (PM > 0) {
+    const float sc = Split<PM>::F16 ? exp2i(e) : 1.f;
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) Ps[((size_t)p * 32 * MT + row) * LDP + col] = t[p];
-          } else {
-            Xs[row * LDX + col] = dz;
-          }
-          if (gdst != nullptr && valid) gdst[row * HID + col] = dz;
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float y4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y4[j] = Split<PM>::F16 ? acc[mt][nt][4 * g + j] * sc : acc[mt][nt][4 * g + j];
+          planes_store4<PM, 32 * MT>(reinterpret_cast<char*>(Xs), 64 * w + 32 * nt + i, 8 * mt + 2 * g + hh, y4);
+        }
+  }
+  auto sweep = [&](auto guarded) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const int col = 64 * w + 32 * nt + i;
+          const float dz = acc[mt][nt][r];
+          if constexpr (PM == 0) Xs[row * LDX + col] = dz;
+          if (gdst != nullptr && (!decltype(guarded)::value || row < rows_here)) gdst[row * HID + col] = dz;
           cs[nt] += dz;
         }
   };
@@ -179,9 +209,9 @@ __device__ __forceinline__ void bwd_seed(const Mlp3BwdArgs& a, float* Xs, float*
 
 // NT (DX only): 16-column tiles of the input-gradient layer handled by the K-split narrow layer (Np1t == 16*NT),
 // or 0 = any Np1t through the row-split path.
-// MASK: see wide_mask_store_colsum (1: sign words m1, m2; 0: saved activations h1, h2; 2: Swish derivatives in h1, h2).
-// NPL: 0 = exact fp32 MFMA; 1..3 = the 256 x 256 GEMM (dz2 W2^T) on the split-precision bf16 core, streaming W2^T's planes.
-template <bool DX, int MT, int NT, int MASK, int NPL = 0>
+// MASK: see wide_mask_apply (1: sign words m1, m2; 0: saved activations h1, h2; 2: Swish derivatives in h1, h2).
+// PM: 0 = exact fp32 MFMA; 1..4 = the 256 x 256 GEMM (dz2 W2^T) on the split-precision core, streaming W2^T's planes.
+template <bool DX, int MT, int NT, int MASK, int PM = 0>
 // (three workgroups per CU only for the sign-word variants: the variants that hold 32 mask / derivative values per lane next to
 //  the accumulators spilled ~26 VGPRs at the 168-register budget; they serve the small generic launches -- V function, DARA
 //  classifier, dynamics pre-training -- where a third resident workgroup buys nothing)
@@ -190,6 +220,7 @@ __global__ __launch_bounds__(NTHREADS, (MT == 1 && MASK == 1) ? 3 : 2) void k_ml
   __shared__ float red[8];
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   constexpr int TB = 32 * MT;
+  constexpr int PMX = PM > 0 ? PM : 1;
   const int m = blockIdx.y;
   const long long row0 = (long long)blockIdx.x * TB;
   const int rows_here = (int)min((long long)TB, a.rows - row0);
@@ -205,6 +236,7 @@ __global__ __launch_bounds__(NTHREADS, (MT == 1 && MASK == 1) ? 3 : 2) void k_ml
   float* dz2 = a.dz2 ? a.dz2 + ((long long)m * a.rows + row0) * HID : nullptr;
   float* dz1 = a.dz1 ? a.dz1 + ((long long)m * a.rows + row0) * HID : nullptr;
   float* dbp = a.dbp + ((long long)blockIdx.x * gridDim.y + m) * (2 * HID + a.Np3);
+  float* scr = reinterpret_cast<float*>(reinterpret_cast<char*>(Xs) + split_scr_offset<PMX, TB>());   // tile maximum (f16 mode)
 
   TR(0);
   WideRing ring;
@@ -225,25 +257,31 @@ __global__ __launch_bounds__(NTHREADS, (MT == 1 && MASK == 1) ? 3 : 2) void k_ml
   wide_zero<MT>(acc);
   wide_gemm<MT>(Xs, w3t, a.Np3, acc, ring);
   TR(2);
-  constexpr int NPLX = NPL > 0 ? NPL : 1;
-  BfRing<NPLX> bring;
-  const bf16x8* w2tp = NPL > 0 ? reinterpret_cast<const bf16x8*>(a.w2t_planes + m * a.planes_ms) : nullptr;
-  if constexpr (NPL > 0) bf_prefetch<NPLX>(w2tp, bring);
+  BfRing<PMX> bring;
+  const s16x8* w2tp = PM > 0 ? reinterpret_cast<const s16x8*>(a.w2t_planes + m * a.planes_ms) : nullptr;
+  if constexpr (PM > 0) bf_prefetch<PMX>(w2tp, bring);
   else wide_prefetch(w2t, HID, ring);             // next layer's first fragments overlap the mask epilogue
+  int e2 = 0;
+  {
+    const float mx = wide_mask_apply<MT, MASK>(acc, h2, m2, rows_here, 1.f);
+    if constexpr (PM == 4) f16_tile_max_put(mx, scr);
+  }
   lds_barrier();
-  wide_mask_store_colsum<MT, MASK, NPL>(acc, Xs, h2, m2, dz2, rows_here, cs);
+  if constexpr (PM == 4) e2 = f16_scale_exp(f16_tile_max_get(scr));
+  wide_store_colsum<MT, PM>(acc, Xs, dz2, rows_here, e2, cs);
   if (lane < 32) { dbp[HID + 64 * w + lane] = cs[0]; dbp[HID + 64 * w + 32 + lane] = cs[1]; }
   lds_barrier();
   TR(3);
   // dh1 = dz2 * W2^T ; dz1 = dh1 * [h1 > 0]
   wide_zero<MT>(acc);
-  if constexpr (NPL > 0) bf_gemm<MT, NPLX>(reinterpret_cast<const __bf16*>(Xs), 32 * MT, w2tp, acc, bring);
+  if constexpr (PM > 0) bf_gemm<MT, PMX, TB>(reinterpret_cast<const char*>(Xs), w2tp, acc, bring);
   else wide_gemm<MT>(Xs, w2t, HID, acc, ring);
   TR(4);
   NarrowRegs<(NT > 0 ? NT : 1)> br;
   if constexpr (DX && NT > 0) narrow_prefetch<NT>(w1t, 16 * NT, br);
+  wide_mask_apply<MT, MASK>(acc, h1, m1, rows_here, PM == 4 ? exp2i(-(e2 + F16_WSHIFT)) : 1.f);
   lds_barrier();
-  wide_mask_store_colsum<MT, MASK>(acc, Xs, h1, m1, dz1, rows_here, cs);
+  wide_store_colsum<MT, 0>(acc, Xs, dz1, rows_here, 0, cs);
   if (lane < 32) { dbp[64 * w + lane] = cs[0]; dbp[64 * w + 32 + lane] = cs[1]; }
   TR(5);
   if constexpr (DX) {
@@ -261,8 +299,7 @@ __global__ __launch_bounds__(NTHREADS, (MT == 1 && MASK == 1) ? 3 : 2) void k_ml
 
 template <bool DX, int MT, int NT, int BITS, int NPL = 0>
 static int launch_bwd_t(const Mlp3BwdArgs& a, int members, hipStream_t st) {
-  constexpr size_t f32b = (size_t)32 * MT * LDX * sizeof(float), plb = (size_t)NPL * 32 * MT * LDP * sizeof(__bf16);
-  constexpr size_t lds = f32b > plb ? f32b : plb;
+  constexpr size_t lds = split_lds_bytes<(NPL > 0 ? NPL : 1), 32 * MT>();
   static bool once = false;
   if (!once) {
     int rc = allow_big_lds(k_mlp3_bwd<DX, MT, NT, BITS, NPL>, lds);
@@ -315,7 +352,7 @@ int launch_mlp3_bwd(const Mlp3BwdArgs& a, int members, bool with_dx, int tile_ro
   }
   if (a.prec != 0 && a.w2t_planes != nullptr && a.m1 != nullptr && a.m2 != nullptr && tile_rows == 32)
     return a.prec == 1 ? launch_bwd_bf<1>(a, members, with_dx, st) : a.prec == 2 ? launch_bwd_bf<2>(a, members, with_dx, st)
-                                                                                 : launch_bwd_bf<3>(a, members, with_dx, st);
+         : a.prec == 3 ? launch_bwd_bf<3>(a, members, with_dx, st) : launch_bwd_bf<4>(a, members, with_dx, st);
   return a.m1 != nullptr && a.m2 != nullptr ? launch_bwd_masks<1>(a, members, with_dx, tile_rows, st)
                                             : launch_bwd_masks<0>(a, members, with_dx, tile_rows, st);
 }

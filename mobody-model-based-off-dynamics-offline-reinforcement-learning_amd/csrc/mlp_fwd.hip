@@ -212,7 +212,7 @@ extern "C" int mobody_mlp3_forward(const float* blob, const float* blob_T, int p
   a.out = out; a.out_mstride = rows * out_dim; a.out_ld = out_dim;
   a.save_x = save_x; a.save_h1 = save_h1; a.save_h2 = save_h2;
   a.out_mode = out_mode; a.max_action = max_action;
-  MB_REQUIRE(precision >= 0 && precision <= 3 && (precision == 0 || blob_T), "mobody_mlp3_forward: precision %d needs the T blob", precision);
+  MB_REQUIRE(precision >= 0 && precision <= 4 && (precision == 0 || blob_T), "mobody_mlp3_forward: precision %d needs the T blob", precision);
   if (precision == 0) return launch_mlp3_fwd(a, members, ACT_RELU, as_stream(stream));
   a.w2_planes = reinterpret_cast<const unsigned short*>(blob_T + L.w2p);
   a.planes_ms = 2 * L.t_member_floats;

@@ -1,8 +1,8 @@
-// Fused 3-layer MLP forward with the 256 x 256 layer on the split-precision bf16 MFMA core (tile_bf.h): throughput modes
-// "bf16" / "bf16x2" / "bf16x3" of the actor / twin-Q / reward-head forwards.  Layer 1 (K = the padded input width) and
-// the output layer stay on exact fp32 MFMA; layer 1's epilogue writes its activations as NPL bf16 planes over the fp32
-// image (same LDS region: every layer separates its reads from its writes by a barrier), layer 2 contracts the planes
-// with the weight planes kept in the T blob and writes an fp32 image for the output layer.
+// Fused 3-layer MLP forward with the 256 x 256 layer on the split-precision MFMA core (tile_bf.h): modes "bf16" / "bf16x2" /
+// "bf16x3" / "f16x2" of the actor / twin-Q / reward-head forwards.  Layer 1 (K = the padded input width) and the output
+// layer stay on exact fp32 MFMA; layer 1's epilogue writes its activations as 16-bit planes over the fp32 image (same LDS
+// region: every layer separates its reads from its writes by a barrier), layer 2 contracts the planes with the weight
+// planes kept in the T blob and writes an fp32 image for the output layer.
 #include <stdlib.h>
 
 #include "common.h"
@@ -10,15 +10,16 @@
 
 namespace mobody {
 
-template <int ACT, int NPL, int RG, int NT>
+template <int ACT, int PM, int RG, int NT>
 __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, float* Xs) {
   constexpr int MT = 1, TB = 32 * RG;
-  __bf16* Ps = reinterpret_cast<__bf16*>(Xs);
+  char* Ps = reinterpret_cast<char*>(Xs);
+  float* scr = reinterpret_cast<float*>(Ps + split_scr_offset<PM, TB>());
   const long long row0 = (long long)blockIdx.x * TB;
   const int rows_here = (int)min((long long)TB, a.rows - row0);
   const bool full = rows_here == TB;
   const float* w1 = a.w1 + m * a.sw1;
-  const bf16x8* w2b = reinterpret_cast<const bf16x8*>(a.w2_planes + m * a.planes_ms);
+  const s16x8* w2b = reinterpret_cast<const s16x8*>(a.w2_planes + m * a.planes_ms);
   const float* w3 = a.w3 + m * a.sw3;
   const float* b3 = a.b3 + m * a.sb3;
   TR(0);
@@ -47,12 +48,12 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
   uint32_t* mask1 = a.mask1 ? a.mask1 + mtile : nullptr;
   uint32_t* mask2 = a.mask2 ? a.mask2 + mtile : nullptr;
   const int mg = (rows_here + 31) / 32;
-  BfRing<NPL> bring;
-  wide_layer_to_planes<ACT, MT, NPL>(Xs, Ps, TB, w1, a.b1 + m * a.sb1, a.Kp1, ring,
+  BfRing<PM> bring;
+  const int e1 = wide_layer_to_planes<ACT, MT, PM, TB>(Xs, Ps, scr, w1, a.b1 + m * a.sb1, a.Kp1, ring,
                                      [=](auto guarded, int row, int col, float y) {
                                        if (h1 != nullptr && (!decltype(guarded)::value || row < rows_here)) h1[row * HID + col] = y;
                                      },
-                                     [&] { bf_prefetch<NPL>(w2b, bring); }, mask1, full, mg);
+                                     [&] { bf_prefetch<PM>(w2b, bring); }, mask1, full, mg);
   TR(2);
   auto save_h2 = [=](auto guarded, int row, int col, float y) {
     if (h2 != nullptr && (!decltype(guarded)::value || row < rows_here)) h2[row * HID + col] = y;
@@ -70,55 +71,54 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
     NarrowRegs<NT> br;
     const int mycol = threadIdx.x % (16 * NT);
     float bias;
-    bf_layer<ACT, MT, NPL>(Xs, Ps, TB, w2b, a.b2 + m * a.sb2, bring, save_h2, [&] {
+    bf_layer<ACT, MT, PM, TB>(Xs, Ps, e1, w2b, a.b2 + m * a.sb2, bring, save_h2, [&] {
       narrow_prefetch<NT>(w3, 16 * NT, br);
       bias = b3[mycol < a.nout ? mycol : 0];
     }, mask2, full, mg);
     TR(4);
     narrow_run<TB / 16, NT>(Xs, br, [&](int row, int col, float v) { emit(row, col, v, bias); });
   } else {
-    bf_layer<ACT, MT, NPL>(Xs, Ps, TB, w2b, a.b2 + m * a.sb2, bring, save_h2, [] {}, mask2, full, mg);
+    bf_layer<ACT, MT, PM, TB>(Xs, Ps, e1, w2b, a.b2 + m * a.sb2, bring, save_h2, [] {}, mask2, full, mg);
     narrow_layer(Xs, w3, HID, a.Np3, [&](int row, int col, float v) { emit(row, col, v, b3[col < a.nout ? col : 0]); }, TB);
   }
   TR(5);
 }
 
 // one or two independent networks per launch (blockIdx.y < members_a -> net a), as k_mlp3_fwd2
-template <int ACT, int NPL, int RG, int NT>
+template <int ACT, int PM, int RG, int NT>
 __global__ __launch_bounds__(NTHREADS * RG, 2) void k_mlp3_fwd_bf(Mlp3FwdArgs a, Mlp3FwdArgs b, int members_a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   const bool second = (int)blockIdx.y >= members_a;
   const Mlp3FwdArgs s = second ? b : a;
   if ((long long)blockIdx.x * (32 * RG) >= s.rows) return;
-  mlp3_fwd_bf_tile<ACT, NPL, RG, NT>(s, second ? (int)blockIdx.y - members_a : (int)blockIdx.y, Xs);
+  mlp3_fwd_bf_tile<ACT, PM, RG, NT>(s, second ? (int)blockIdx.y - members_a : (int)blockIdx.y, Xs);
 }
 
-template <int ACT, int NPL, int RG, int NT>
+template <int ACT, int PM, int RG, int NT>
 static int launch_bf_t(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, hipStream_t st) {
-  constexpr size_t f32b = (size_t)32 * RG * LDX * sizeof(float), plb = (size_t)NPL * 32 * RG * LDP * sizeof(__bf16);
-  constexpr size_t lds = f32b > plb ? f32b : plb;
+  constexpr size_t lds = split_lds_bytes<PM, 32 * RG>();
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_mlp3_fwd_bf<ACT, NPL, RG, NT>, 160 * 1024);
+    int rc = allow_big_lds(k_mlp3_fwd_bf<ACT, PM, RG, NT>, 160 * 1024);
     if (rc) return rc;
     once = true;
   }
   const long long rows = a.rows > b.rows ? a.rows : b.rows;
   ProfScope prof(PROF_MLP_FWD, st);
-  hipLaunchKernelGGL((k_mlp3_fwd_bf<ACT, NPL, RG, NT>), dim3((unsigned)cdiv(rows, 32 * RG), (unsigned)(members_a + members_b)),
+  hipLaunchKernelGGL((k_mlp3_fwd_bf<ACT, PM, RG, NT>), dim3((unsigned)cdiv(rows, 32 * RG), (unsigned)(members_a + members_b)),
                      dim3(NTHREADS * RG), lds, st, a, b, members_a);
   MB_LAUNCH_OK("k_mlp3_fwd_bf");
   return 0;
 }
 
-template <int ACT, int NPL, int RG>
+template <int ACT, int PM, int RG>
 static int launch_bf_nt(const Mlp3FwdArgs& a, int ma, const Mlp3FwdArgs& b, int mb, hipStream_t st) {
   const int np3 = a.rows > 0 ? a.Np3 : b.Np3;
-  return np3 == 16 ? launch_bf_t<ACT, NPL, RG, 1>(a, ma, b, mb, st) : np3 == 32 ? launch_bf_t<ACT, NPL, RG, 2>(a, ma, b, mb, st)
-                                                                              : launch_bf_t<ACT, NPL, RG, 0>(a, ma, b, mb, st);
+  return np3 == 16 ? launch_bf_t<ACT, PM, RG, 1>(a, ma, b, mb, st) : np3 == 32 ? launch_bf_t<ACT, PM, RG, 2>(a, ma, b, mb, st)
+                                                                              : launch_bf_t<ACT, PM, RG, 0>(a, ma, b, mb, st);
 }
 
-// prec: 1 bf16, 2 bf16x2, 3 bf16x3.  Two ReLU nets (either may be empty: rows <= 0) or one Swish net.
+// prec: 1 bf16, 2 bf16x2, 3 bf16x3, 4 f16x2.  Two ReLU nets (either may be empty: rows <= 0) or one Swish net.
 int launch_mlp3_fwd_bf(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, int act, int prec, hipStream_t st) {
   // row groups per workgroup: 1 = 32-row tiles of 4 waves (measured best: twin-Q forward at 10 240 rows 28.8 us in bf16x3
   // against 41.5 us with two row groups sharing each weight fragment, 39.5 us in fp32); MOBODY_BF_RG=2 is a tuning aid
@@ -127,9 +127,9 @@ int launch_mlp3_fwd_bf(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b
   Mlp3FwdArgs x = a, y = b; int mx = members_a, my = members_b;
   if (x.rows <= 0) { x = b; mx = members_b; y.rows = 0; my = 0; }
   if (y.rows <= 0) my = 0;
-#define BF_CASE(ACT, NPL) (rg == 1 ? launch_bf_nt<ACT, NPL, 1>(x, mx, y, my, st) : launch_bf_nt<ACT, NPL, 2>(x, mx, y, my, st))
-  if (act == ACT_SWISH) return prec == 1 ? BF_CASE(ACT_SWISH, 1) : prec == 2 ? BF_CASE(ACT_SWISH, 2) : BF_CASE(ACT_SWISH, 3);
-  return prec == 1 ? BF_CASE(ACT_RELU, 1) : prec == 2 ? BF_CASE(ACT_RELU, 2) : BF_CASE(ACT_RELU, 3);
+#define BF_CASE(ACT, PM) (rg == 1 ? launch_bf_nt<ACT, PM, 1>(x, mx, y, my, st) : launch_bf_nt<ACT, PM, 2>(x, mx, y, my, st))
+  if (act == ACT_SWISH) return prec == 1 ? BF_CASE(ACT_SWISH, 1) : prec == 2 ? BF_CASE(ACT_SWISH, 2) : prec == 3 ? BF_CASE(ACT_SWISH, 3) : BF_CASE(ACT_SWISH, 4);
+  return prec == 1 ? BF_CASE(ACT_RELU, 1) : prec == 2 ? BF_CASE(ACT_RELU, 2) : prec == 3 ? BF_CASE(ACT_RELU, 3) : BF_CASE(ACT_RELU, 4);
 #undef BF_CASE
 }
 

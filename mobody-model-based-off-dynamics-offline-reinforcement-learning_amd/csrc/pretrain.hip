@@ -647,9 +647,9 @@ extern "C" int mobody_pretrain_transpose(int S, int A, const float* blob, float*
   int rc = mobody_pretrain_layout(S, A, &L);
   if (rc) return rc;
   MB_REQUIRE(blob && blob_T, "mobody_pretrain_transpose: null pointer");
-  rc = mobody_mlp_transpose(S, 2 * LATENT, NENS, blob + L.off_enc, blob_T + L.t_off_enc, stream);
-  if (!rc) rc = mobody_mlp_transpose(LATENT, S, NENS, blob + L.off_tr, blob_T + L.t_off_tr, stream);
-  if (!rc) rc = mobody_mlp_transpose(2 * S + A, 2, NENS, blob + L.off_rw, blob_T + L.t_off_rw, stream);
+  rc = mobody_mlp_transpose(S, 2 * LATENT, NENS, blob + L.off_enc, blob_T + L.t_off_enc, 0, stream);
+  if (!rc) rc = mobody_mlp_transpose(LATENT, S, NENS, blob + L.off_tr, blob_T + L.t_off_tr, 0, stream);
+  if (!rc) rc = mobody_mlp_transpose(2 * S + A, 2, NENS, blob + L.off_rw, blob_T + L.t_off_rw, 0, stream);
   return rc;
 }
 

@@ -92,14 +92,22 @@ int launch_wgrad(WgradArgs a, hipStream_t st);
 // on the host and rounded to fp32 once, as torch does when it multiplies a fp32 tensor by a Python float.
 struct AdamConsts { float w1, b2, w2, step_size, bc2_sqrt, eps, tau, one_minus_tau, gscale; };
 
-// W2[k][n] = w -> the three bf16 terms of w in the planes of W2 (as B[k][n]) and of W2^T (as B[n][k]) of a member's T blob
-__device__ __forceinline__ void write_w2_planes(float* t_member, const MobodyMlpLayout& L, int k, int n, float w) {
-  __bf16 t[3];
-  bf_split<3>(w, t);
-  __bf16* p2 = reinterpret_cast<__bf16*>(t_member + L.w2p);
-  __bf16* p2t = reinterpret_cast<__bf16*>(t_member + L.w2tp);
+// W2[k][n] = w -> its terms in the planes of W2 (as B[k][n]) and of W2^T (as B[n][k]) of a member's T blob: the three bf16
+// terms (precision modes 0-3 share them), or -- precision 4, "f16x2" -- the two fp16 terms of w * 2^F16_WSHIFT in planes 0, 1
+__device__ __forceinline__ void write_w2_planes(float* t_member, const MobodyMlpLayout& L, int k, int n, float w, int precision) {
+  short* p2 = reinterpret_cast<short*>(t_member + L.w2p);
+  short* p2t = reinterpret_cast<short*>(t_member + L.w2tp);
+  if (precision == 4) {
+    short t[2];
+    split_terms<4>(w * exp2i(F16_WSHIFT), t);
 #pragma unroll
-  for (int p = 0; p < 3; ++p) { p2[bf_plane_idx(p, k, n)] = t[p]; p2t[bf_plane_idx(p, n, k)] = t[p]; }
+    for (int p = 0; p < 2; ++p) { p2[bf_plane_idx(p, k, n)] = t[p]; p2t[bf_plane_idx(p, n, k)] = t[p]; }
+  } else {
+    short t[3];
+    split_terms<3>(w, t);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { p2[bf_plane_idx(p, k, n)] = t[p]; p2t[bf_plane_idx(p, n, k)] = t[p]; }
+  }
 }
 
 // Destination of parameter entry (member-local offset o) inside the member's T blob, or -1 (biases, padding rows).
@@ -133,6 +141,7 @@ struct AdamTarget {
   float lr;
   int on;                                   // k_grad_reduce only: 0 = just write the gradient
   long long* bump;                          // k_grad_reduce only: device word incremented by one thread (not t_dev), or null
+  int precision;                            // format of the W2 planes kept in blob_T / target_T (write_w2_planes)
 };
 
 // Bias corrections of a device-side step count (graph replay), formed ONCE per workgroup in double: thread 0 computes,
@@ -178,8 +187,8 @@ __device__ __forceinline__ void adam_element(const AdamTarget& a, const MobodyMl
     if (o >= L.w2 && o < L.b2) {                     // a W2 element (wide storage): its planes
       const long long oo = o - L.w2, g = oo >> 2;
       const int k = (int)(g / HID) * 4 + (int)(oo & 3), n = (int)(g % HID);
-      if (a.blob_T != nullptr) write_w2_planes(a.blob_T + (long long)mem * L.t_member_floats, L, k, n, pj);
-      if (a.target_T != nullptr && a.target != nullptr) write_w2_planes(a.target_T + (long long)mem * L.t_member_floats, L, k, n, tj);
+      if (a.blob_T != nullptr) write_w2_planes(a.blob_T + (long long)mem * L.t_member_floats, L, k, n, pj, a.precision);
+      if (a.target_T != nullptr && a.target != nullptr) write_w2_planes(a.target_T + (long long)mem * L.t_member_floats, L, k, n, tj, a.precision);
     }
   }
 }

@@ -161,7 +161,7 @@ int launch_adam(const AdamTarget& a, const float* g, const MobodyMlpLayout& L, h
 
 // W1 and W2 (and W3T, W2T of the T blob) are 256 columns wide and stored K-interleaved (tile.h wide_idx);
 // W3 and W1T are narrow and row major.
-__global__ __launch_bounds__(256) void k_mlp_transpose(MobodyMlpLayout L, const float* blob, float* bt) {
+__global__ __launch_bounds__(256) void k_mlp_transpose(MobodyMlpLayout L, const float* blob, float* bt, int precision) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= L.t_total_floats) return;
   const int m = (int)(j / L.t_member_floats);
@@ -170,7 +170,11 @@ __global__ __launch_bounds__(256) void k_mlp_transpose(MobodyMlpLayout L, const 
   if (o >= L.w2p) {                                // bf16 planes of W2 / W2^T: one thread per float slot writes nothing here;
     if (o >= L.w2p + HID * HID) return;            // the first 65536 threads of the region each split one weight
     const int e = (int)(o - L.w2p), k = e / HID, n = e % HID;
-    write_w2_planes(bt + (long long)m * L.t_member_floats, L, k, n, src[L.w2 + wide_idx(k, n)]);
+    write_w2_planes(bt + (long long)m * L.t_member_floats, L, k, n, src[L.w2 + wide_idx(k, n)], precision);
+    if (precision == 4) {                          // the unused third plane slot: defined contents (a rebuilt T blob compares equal)
+      short* tm = reinterpret_cast<short*>(bt + (long long)m * L.t_member_floats);
+      tm[2 * L.w2p + bf_plane_idx(2, k, n)] = 0; tm[2 * L.w2tp + bf_plane_idx(2, n, k)] = 0;
+    }
     return;
   }
   float val;
@@ -224,7 +228,7 @@ static int fwd_one(const Mlp3FwdArgs& a, int ma, int prec, hipStream_t st) {
   return prec == 0 ? launch_mlp3_fwd(a, ma, ACT_RELU, st) : launch_mlp3_fwd_bf(a, ma, Mlp3FwdArgs{}, 0, ACT_RELU, prec, st);
 }
 static int check_prec(const MobodyHyper* h, const char* who, bool have_planes) {
-  MB_REQUIRE(h->precision >= 0 && h->precision <= 3, "%s: precision must be 0 (f32), 1 (bf16), 2 (bf16x2) or 3 (bf16x3)", who);
+  MB_REQUIRE(h->precision >= 0 && h->precision <= 4, "%s: precision must be 0 (f32), 1 (bf16), 2 (bf16x2), 3 (bf16x3) or 4 (f16x2)", who);
   MB_REQUIRE(h->precision == 0 || have_planes, "%s: the split-precision modes need the T blobs (bf16 planes) of every net", who);
   return 0;
 }
@@ -260,7 +264,7 @@ extern "C" int64_t mobody_train_workspace(const MobodyTrainDims* d) {
 }
 
 static AdamTarget adam_target(float* blob, float* blob_T, float* m, float* v, float* target, int64_t t, const int64_t* t_dev,
-                              float lr, float tau, float grad_scale);
+                              float lr, float tau, float grad_scale, int precision);
 
 static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* actor_blob_T,
                        const float* q_blob, const float* q_blob_T, const float* qtarg_blob, const float* qtarg_blob_T,
@@ -331,7 +335,7 @@ extern "C" int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper*
   MB_REQUIRE(h && q_blob && q_blob_T && qtarg_blob && m && v, "mobody_critic_update: null pointer");
   MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_critic_update: step t must be >= 1");
   MB_REQUIRE(bump == nullptr || bump != t_dev, "mobody_critic_update: bump must not be the step word the launch reads");
-  AdamTarget at = adam_target(q_blob, q_blob_T, m, v, qtarg_blob, t, t_dev, lr, h->tau, 1.f);
+  AdamTarget at = adam_target(q_blob, q_blob_T, m, v, qtarg_blob, t, t_dev, lr, h->tau, 1.f, h->precision);
   at.target_T = qtarg_blob_T;
   at.bump = (long long*)bump;
   return critic_impl(d, h, actor_blob, actor_blob_T, q_blob, q_blob_T, qtarg_blob, qtarg_blob_T, state, action, next_state, reward,
@@ -429,23 +433,26 @@ extern "C" int mobody_actor_update(const MobodyTrainDims* d, const MobodyHyper* 
   MB_REQUIRE(actor_blob && actor_blob_T && m && v, "mobody_actor_update: null pointer");
   MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_actor_update: step t must be >= 1");
   return actor_backward_impl(d, h, actor_blob, actor_blob_T, q_blob, q_blob_T, state, action, stats, v_true, nullptr,
-                             adam_target(actor_blob, actor_blob_T, m, v, nullptr, t, t_dev, lr, -1.f, 1.f), loss_out,
+                             adam_target(actor_blob, actor_blob_T, m, v, nullptr, t, t_dev, lr, -1.f, 1.f, h ? h->precision : 0), loss_out,
                              workspace, stream);
 }
 
-extern "C" int mobody_mlp_transpose(int in_dim, int out_dim, int members, const float* blob, float* blob_T, void* stream) {
+extern "C" int mobody_mlp_transpose(int in_dim, int out_dim, int members, const float* blob, float* blob_T, int precision,
+                                    void* stream) {
   MobodyMlpLayout L;
   int rc = mobody_mlp_layout(in_dim, out_dim, members, &L);
   if (rc) return rc;
   MB_REQUIRE(blob && blob_T, "mobody_mlp_transpose: null pointer");
-  hipLaunchKernelGGL(k_mlp_transpose, dim3((unsigned)cdiv(L.t_total_floats, 256)), dim3(256), 0, as_stream(stream), L, blob, blob_T);
+  MB_REQUIRE(precision >= 0 && precision <= 4, "mobody_mlp_transpose: precision must be 0..4");
+  hipLaunchKernelGGL(k_mlp_transpose, dim3((unsigned)cdiv(L.t_total_floats, 256)), dim3(256), 0, as_stream(stream), L, blob, blob_T,
+                     precision);
   MB_LAUNCH_OK("k_mlp_transpose");
   return 0;
 }
 
 // torch.optim.Adam scalar bookkeeping in double, as the reference's host code does
 static AdamTarget adam_target(float* blob, float* blob_T, float* m, float* v, float* target, int64_t t, const int64_t* t_dev,
-                              float lr, float tau, float grad_scale) {
+                              float lr, float tau, float grad_scale, int precision) {
   const double tt = t_dev ? 1.0 : (double)t;
   const double bc1 = 1.0 - pow(0.9, tt), bc2 = 1.0 - pow(0.999, tt);
   AdamTarget a{};
@@ -454,19 +461,20 @@ static AdamTarget adam_target(float* blob, float* blob_T, float* m, float* v, fl
   a.c.w1 = (float)(1.0 - 0.9); a.c.b2 = (float)0.999; a.c.w2 = (float)(1.0 - 0.999);
   a.c.step_size = (float)((double)lr / bc1); a.c.bc2_sqrt = (float)sqrt(bc2); a.c.eps = 1e-8f;
   a.c.tau = tau; a.c.one_minus_tau = (float)(1.0 - (double)tau); a.c.gscale = grad_scale;
-  a.t_dev = (const long long*)t_dev; a.lr = lr; a.on = 1;
+  a.t_dev = (const long long*)t_dev; a.lr = lr; a.on = 1; a.precision = precision;
   return a;
 }
 
 static int adam_impl(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad, float* m,
                      float* v, float* target, float* target_T, int64_t t, const int64_t* t_dev, float lr, float tau,
-                     float grad_scale, void* stream) {
+                     float grad_scale, int precision, void* stream) {
   MobodyMlpLayout L;
   int rc = mobody_mlp_layout(in_dim, out_dim, members, &L);
   if (rc) return rc;
   MB_REQUIRE(blob && grad && m && v, "mobody_adam_polyak: null pointer");
   MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_adam_polyak: step t must be >= 1");
-  AdamTarget a = adam_target(blob, blob_T, m, v, target, t, t_dev, lr, tau, grad_scale);
+  MB_REQUIRE(precision >= 0 && precision <= 4, "mobody_adam_polyak: precision must be 0..4");
+  AdamTarget a = adam_target(blob, blob_T, m, v, target, t, t_dev, lr, tau, grad_scale, precision);
   a.target_T = a.target ? target_T : nullptr;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(k_adam, dim3((unsigned)cdiv(L.total_floats, 256)), dim3(256), 0, st, a, grad, (long long)L.total_floats, L);
@@ -476,15 +484,15 @@ static int adam_impl(int in_dim, int out_dim, int members, float* blob, float* b
 
 extern "C" int mobody_adam_polyak(int in_dim, int out_dim, int members, float* blob, float* blob_T, const float* grad,
                                   float* m, float* v, float* target, float* target_T, int64_t t, float lr, float tau,
-                                  float grad_scale, void* stream) {
-  return adam_impl(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, target_T, t, nullptr, lr, tau, grad_scale, stream);
+                                  float grad_scale, int precision, void* stream) {
+  return adam_impl(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, target_T, t, nullptr, lr, tau, grad_scale, precision, stream);
 }
 
 extern "C" int mobody_adam_polyak_dev(int in_dim, int out_dim, int members, float* blob, float* blob_T,
                                       const float* grad, float* m, float* v, float* target, float* target_T,
-                                      const int64_t* t_dev, float lr, float tau, float grad_scale, void* stream) {
+                                      const int64_t* t_dev, float lr, float tau, float grad_scale, int precision, void* stream) {
   MB_REQUIRE(t_dev != nullptr, "mobody_adam_polyak_dev: t_dev is null");
-  return adam_impl(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, target_T, 0, t_dev, lr, tau, grad_scale, stream);
+  return adam_impl(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, target_T, 0, t_dev, lr, tau, grad_scale, precision, stream);
 }
 
 // ---- PAR reward penalty: r -= coef * mean_d (s'_true - s'_model)^2   (mobody.py:428-434) ----

@@ -29,8 +29,9 @@ class Engine:
         self.actor = packing.pack_mlp([{k[len("network."):]: v for k, v in pa.items()}], S, A, dev)
         self.q = packing.pack_mlp(pq, S + A, 1, dev, prefixes=["network1.", "network2."])
         self.qt = self.q.clone()
-        self.actor_T = ops.mlp_transpose(self.actor, S, A, 1)
-        self.q_T = ops.mlp_transpose(self.q, S + A, 1, 2)
+        self.prec = ops.prec_id(ops.default_mfma())    # plane format of the T blobs (re-built when a step asks for another)
+        self.actor_T = ops.mlp_transpose(self.actor, S, A, 1, precision=self.prec)
+        self.q_T = ops.mlp_transpose(self.q, S + A, 1, 2, precision=self.prec)
         self.qt_T = self.q_T.clone()                   # the target's T blob (its W2 planes follow the Polyak update)
         z = torch.zeros_like
         self.ma, self.va, self.mq, self.vq = z(self.actor), z(self.actor), z(self.q), z(self.q)
@@ -46,18 +47,24 @@ class Engine:
         N = b[0].shape[0]
         dims = dims or ops.train_dims(S, A, N, n_true)
         hyp = ops.hyper(cfg)
+        if (hyp.precision == 4) != (self.prec == 4):   # 'f16x2' keeps its own W2 planes; the other modes share theirs
+            ops.mlp_transpose(self.actor, S, A, 1, out=self.actor_T, precision=hyp.precision)
+            ops.mlp_transpose(self.q, S + A, 1, 2, out=self.q_T, precision=hyp.precision)
+            ops.mlp_transpose(self.qt, S + A, 1, 2, out=self.qt_T, precision=hyp.precision)
+        self.prec = hyp.precision
         ws = ops.train_workspace(dims, self.dev)
         ops.critic_step(dims, hyp, self.actor, self.q, self.q_T, self.qt, b, self.gq, self.loss[0:1], ws,
                         actor_blob_T=self.actor_T, qtarg_blob_T=self.qt_T)
         if apply:
             self.t += 1
             ops.adam_polyak(S + A, 1, 2, self.q, self.q_T, self.gq, self.mq, self.vq, self.qt, self.t, cfg["critic_lr"], cfg["tau"],
-                            target_T=self.qt_T)
+                            target_T=self.qt_T, precision=self.prec)
         ops.actor_forward(dims, hyp, self.actor, self.q, b[0], b[1], self.stats, ws, actor_blob_T=self.actor_T, q_blob_T=self.q_T)
         ops.actor_backward(dims, hyp, self.actor, self.actor_T, self.q, self.q_T, b[0], b[1], self.stats, self.ga,
                            self.loss[1:3], ws)
         if apply:
-            ops.adam_polyak(S, A, 1, self.actor, self.actor_T, self.ga, self.ma, self.va, None, self.t, cfg["actor_lr"])
+            ops.adam_polyak(S, A, 1, self.actor, self.actor_T, self.ga, self.ma, self.va, None, self.t, cfg["actor_lr"],
+                            precision=self.prec)
         torch.cuda.synchronize()
         return dict(q_loss=float(self.loss[0]), pi_loss=float(self.loss[1]), bc_loss=float(self.loss[2]))
 

@@ -31,7 +31,7 @@ def rng_index(seed, stream_id, call, n, bound, device):
 
 
 def prec_id(mfma):
-    """'f32' | 'bf16' | 'bf16x2' | 'bf16x3' (or the integer id) -> MobodyHyper.precision."""
+    """'f32' | 'bf16' | 'bf16x2' | 'bf16x3' | 'f16x2' (or the integer id) -> MobodyHyper.precision."""
     return mfma if isinstance(mfma, int) else _lib.PRECISIONS[mfma]
 
 
@@ -42,10 +42,11 @@ def default_mfma():
     return os.environ.get("MOBODY_MFMA", "f32")
 
 
-def dyn_planes(blob, S, A, out=None):
-    """bf16 planes of zs2 / transition2 / reward_model2 for the split-precision modes."""
+def dyn_planes(blob, S, A, out=None, precision=3):
+    """16-bit planes of zs2 / transition2 / reward_model2 in the format of the split-precision mode `precision`
+    (modes 1-3 share the three bf16 planes; 'f16x2' has its own two fp16 planes)."""
     pl = out if out is not None else torch.empty(load().mobody_dyn_planes_floats(), dtype=torch.float32, device=blob.device)
-    check(load().mobody_dyn_planes(ptr(blob), S, A, ptr(pl), cur_stream()), "mobody_dyn_planes")
+    check(load().mobody_dyn_planes(ptr(blob), S, A, ptr(pl), prec_id(precision), cur_stream()), "mobody_dyn_planes")
     return pl
 
 
@@ -145,11 +146,13 @@ def train_workspace(dims, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
-def mlp_transpose(blob, in_dim, out_dim, members, out=None):
+def mlp_transpose(blob, in_dim, out_dim, members, out=None, precision=0):
+    """T blob of a packed MLP; `precision` = the MFMA mode whose W2 plane format it carries."""
     L = _lib.mlp_layout(in_dim, out_dim, members)
     bt = out if out is not None else torch.empty(L.t_total_floats, dtype=torch.float32, device=blob.device)
     assert bt.numel() == L.t_total_floats
-    check(load().mobody_mlp_transpose(in_dim, out_dim, members, ptr(blob), ptr(bt), cur_stream()), "mobody_mlp_transpose")
+    check(load().mobody_mlp_transpose(in_dim, out_dim, members, ptr(blob), ptr(bt), prec_id(precision), cur_stream()),
+          "mobody_mlp_transpose")
     return bt
 
 
@@ -205,9 +208,11 @@ def value_loss_grad(qt, v, n_global):
     return dz3, loss
 
 
-def adam_polyak(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t, lr, tau=-1.0, grad_scale=1.0, target_T=None):
+def adam_polyak(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t, lr, tau=-1.0, grad_scale=1.0, target_T=None,
+                precision=0):
     check(load().mobody_adam_polyak(in_dim, out_dim, members, ptr(blob), ptr(blob_T), ptr(grad), ptr(m), ptr(v),
-                                    ptr(target), ptr(target_T), int(t), float(lr), float(tau), float(grad_scale), cur_stream()),
+                                    ptr(target), ptr(target_T), int(t), float(lr), float(tau), float(grad_scale),
+                                    prec_id(precision), cur_stream()),
           "mobody_adam_polyak")
 
 
@@ -316,10 +321,10 @@ def par_penalty(next_state_true, next_state_model, reward, coef):
 
 
 def adam_polyak_dev(in_dim, out_dim, members, blob, blob_T, grad, m, v, target, t_dev, lr, tau=-1.0, grad_scale=1.0,
-                    target_T=None):
+                    target_T=None, precision=0):
     check(load().mobody_adam_polyak_dev(in_dim, out_dim, members, ptr(blob), ptr(blob_T), ptr(grad), ptr(m), ptr(v),
                                         ptr(target), ptr(target_T), ptr(t_dev), float(lr), float(tau), float(grad_scale),
-                                        cur_stream()), "mobody_adam_polyak_dev")
+                                        prec_id(precision), cur_stream()), "mobody_adam_polyak_dev")
 
 
 def gather_batch_rng(buffers, counts, seeds, call_offsets, counter, sizes, S, A, out, bump=()):

@@ -1,12 +1,14 @@
-"""Split-precision MFMA modes (BASELINE configs[1]: "bf16 MFMA inputs / fp32 accumulate") -- throughput modes of the
-256 x 256 FORWARD layers (actor / twin-Q / target-Q forwards of train(), zs2 / transition2 / reward_model2 of the
-ensemble step); backward passes, weight gradients, optimizer and every narrow layer stay on exact fp32 MFMA.
+"""Split-precision MFMA modes (BASELINE configs[1]: "bf16 MFMA inputs / fp32 accumulate") of the 256 x 256 layers: the
+actor / twin-Q / target-Q forwards and backwards of train() and its 256 x 256 weight-gradient job, zs2 / transition2 /
+reward_model2 of the ensemble step.  Layer 1, every narrow layer, reductions and the optimizer stay exact fp32.
 
     mfma      terms / products      measured deviation from the fp32 kernels (relative to max |output|)
-    'bf16x3'  3 / 6                 ~5e-7   -> held to the SAME tolerances as the fp32 path (1e-5, north_star)
-    'bf16x2'  2 / 3                 ~6e-6   -> 5e-5 here
-    'bf16'    1 / 1                 ~3e-3   -> 3e-2 here
-The default ('f32') is untouched by these tests; every parity test elsewhere runs in it."""
+    'f16x2'   2 fp16 / 3            ~3e-7   -> held to the SAME tolerances as the fp32 path (1e-5, north_star); bench default
+    'bf16x3'  3 bf16 / 6            ~5e-7   -> the same
+    'bf16x2'  2 bf16 / 3            ~6e-6   -> 5e-5 here
+    'bf16'    1 bf16 / 1            ~3e-3   -> 3e-2 here
+The golden-vector suites (test_hip_train / _mirror / _dynamics / _pretrain / _fullsize) run in 'f32' AND in the bench's
+mode through the `mfma` fixture of conftest.py; this file holds what is specific to the split modes."""
 import numpy as np
 import pytest
 import torch
@@ -15,7 +17,8 @@ import golden_util as gu
 from oracle import mobody_oracle as O
 
 pytestmark = pytest.mark.gpu
-TOL = {"bf16x3": 1e-5, "bf16x2": 5e-5, "bf16": 3e-2}
+TOL = {"f16x2": 1e-5, "bf16x3": 1e-5, "bf16x2": 5e-5, "bf16": 3e-2}
+FP32_GRADE = ("f16x2", "bf16x3")
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +33,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16x2", "bf16"])
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "bf16x2", "bf16"])
 @pytest.mark.parametrize("S,A,rows", [(17, 6, 333), (111, 8, 64), (45, 24, 97)])
 def test_mlp3_forward_modes_vs_oracle(mode, S, A, rows, dev):
     from mobody_amd import ops, packing
@@ -38,7 +41,7 @@ def test_mlp3_forward_modes_vs_oracle(mode, S, A, rows, dev):
     s, a, _, _, _ = gu.gi.batch(11, rows, S, A)
     ab = packing.pack_mlp([{k[len("network."):]: v for k, v in pa.items()}], S, A, dev)
     qb = packing.pack_mlp(pq, S + A, 1, dev, prefixes=["network1.", "network2."])
-    aT, qT = ops.mlp_transpose(ab, S, A, 1), ops.mlp_transpose(qb, S + A, 1, 2)
+    aT, qT = ops.mlp_transpose(ab, S, A, 1, precision=mode), ops.mlp_transpose(qb, S + A, 1, 2, precision=mode)
     sd, ad = torch.from_numpy(s).to(dev), torch.from_numpy(a).to(dev)
     with torch.no_grad():
         want_pi = O.actor(O.to_torch(pa), O.T(s), 1.0)
@@ -56,14 +59,14 @@ def test_mlp3_forward_modes_vs_oracle(mode, S, A, rows, dev):
     assert rel(h2[0], hh2) <= TOL[mode]
 
 
-@pytest.mark.parametrize("mode", ["bf16x3", "bf16x2", "bf16"])
+@pytest.mark.parametrize("mode", ["f16x2", "bf16x3", "bf16x2", "bf16"])
 @pytest.mark.parametrize("tag", ["walker", "ant", "pen"])
 def test_dyn_step_modes_vs_reference_golden(mode, tag, dev):
     from mobody_amd import ops, packing, _lib
     g = gu.load(f"g234_dynamics_{tag}")
     S, A = int(g["S"]), int(g["A"])
     blob = packing.pack_dynamics(gu.dyn_params_for(g), S, A, dev)
-    planes = ops.dyn_planes(blob, S, A)
+    planes = ops.dyn_planes(blob, S, A, precision=mode)
     obs, act = torch.from_numpy(g["obs"]).to(dev), torch.from_numpy(g["act"]).to(dev)
     assert rel(ops.dyn_forward(blob, S, A, obs, act, True, planes=planes, precision=mode), g["mean_trg"]) <= TOL[mode]
     assert rel(ops.dyn_forward(blob, S, A, obs, act, False, planes=planes, precision=mode), g["mean_src"]) <= TOL[mode]
@@ -73,18 +76,19 @@ def test_dyn_step_modes_vs_reference_golden(mode, tag, dev):
     for key in ("next_obs", "reward", "raw_reward"):
         assert rel(r[key], g[k + key]) <= TOL[mode], key
     assert rel(r["penalty"], g[k + "penalty"]) <= 20 * TOL[mode]              # a difference of means: relative error amplifies
-    if mode == "bf16x3":
+    if mode in FP32_GRADE:
         assert (r["terminal"].cpu().numpy().astype(bool) == g[k + "terminal"]).all()
 
 
-def test_train_step_bf16x3_meets_the_fp32_parity_bar(dev):
-    """G7 'default' (two train() steps of the reference) with every 256 x 256 forward on the 3-term split core: the same
+@pytest.mark.parametrize("mode", FP32_GRADE)
+def test_train_step_fp32_grade_modes_meet_the_fp32_parity_bar(mode, dev):
+    """G7 'default' (two train() steps of the reference) with every 256 x 256 GEMM on the split core: the same
     assertions and tolerances as tests/test_hip_train.py::test_train_step_vs_reference_golden."""
     from mobody_amd.engine import Engine
     from test_hip_train import close, params_close
     g = gu.load("g7_train_default")
     S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
-    cfg = gu.policy_cfg(S, A, mfma="bf16x3")
+    cfg = gu.policy_cfg(S, A, mfma=mode)
     pa, pq, _ = gu.policy_params(int(g["seed"]), S, A)
     eng = Engine(S, A, pa, pq, dev)
     batch, n_true = gu.g7_batch(cfg, bs, S, A)
@@ -103,10 +107,10 @@ def test_train_step_bf16x3_meets_the_fp32_parity_bar(dev):
                 params_close(gu.sub(v.cpu().numpy()), g[f"s{step}_{nm}_p::{k}"], cfg["critic_lr"])
     # the planes every forward streamed were kept current by the optimizer kernels: rebuilding them changes nothing
     from mobody_amd import _lib, ops
-    assert torch.equal(ops.mlp_transpose(eng.q, S + A, 1, 2), eng.q_T)
-    assert torch.equal(ops.mlp_transpose(eng.actor, S, A, 1), eng.actor_T)
+    assert torch.equal(ops.mlp_transpose(eng.q, S + A, 1, 2, precision=mode), eng.q_T)
+    assert torch.equal(ops.mlp_transpose(eng.actor, S, A, 1, precision=mode), eng.actor_T)
     L = _lib.mlp_layout(S + A, 1, 2)                     # target net: only its W2 planes follow the Polyak update
-    fresh = ops.mlp_transpose(eng.qt, S + A, 1, 2).view(2, L.t_member_floats)
+    fresh = ops.mlp_transpose(eng.qt, S + A, 1, 2, precision=mode).view(2, L.t_member_floats)
     assert torch.equal(fresh[:, L.w2p:L.w2tp], eng.qt_T.view(2, L.t_member_floats)[:, L.w2p:L.w2tp])
 
 
@@ -131,8 +135,9 @@ def test_train_step_lower_modes_vs_oracle(mode, tol, dev):
             assert d <= 10 * tol * scale, (nm, k, d, scale)
 
 
-def test_mirror_graph_steps_bf16x3_track_the_fp32_run(dev):
-    """The mirror in mfma='bf16x3' (device RNG, graph replay, refresh through mobody_rollout at step 1): six train() calls
+@pytest.mark.parametrize("split", FP32_GRADE)
+def test_mirror_graph_steps_fp32_grade_modes_track_the_fp32_run(split, dev):
+    """The mirror in a fp32-grade split mode (device RNG, graph replay, refresh through mobody_rollout at step 1): six train() calls
     stay within 2e-4 of the same run in exact fp32 (identical seeds -> identical minibatches; the step-1 rollout rows differ
     by the mode's ~5e-7), and the W2 planes every forward streams were kept current by the fused optimizer kernels."""
     from mobody_amd import ops, synthetic
@@ -143,7 +148,7 @@ def test_mirror_graph_steps_bf16x3_track_the_fp32_run(dev):
     from mobody_amd.algo.mb_utils.terminal_funs import get_termination_fn
     S, A, bs, task = 17, 6, 256, "walker2d-medium-v2"
     res = {}
-    for mode in ("f32", "bf16x3"):
+    for mode in ("f32", split):
         cfg = gu.policy_cfg(S, A, rng="device", seed=3, mfma=mode, graph=1, batch_size=bs)
         torch.manual_seed(0); np.random.seed(0)
         pol = call_algo("mobody", cfg, 3, dev)
@@ -155,15 +160,15 @@ def test_mirror_graph_steps_bf16x3_track_the_fp32_run(dev):
         for _ in range(6):
             pol.train(src, tar, bs, None, None)
         torch.cuda.synchronize()
-        assert pol._graph is not None and pol.fake_replay_buffer.size > 0 and pol.precision == (3 if mode == "bf16x3" else 0)
+        assert pol._graph is not None and pol.fake_replay_buffer.size > 0 and pol.precision == ops.prec_id(mode)
         res[mode] = {k: v.cpu() for k, v in list(pol.policy.state_dict().items()) + list(pol.q_funcs.state_dict().items())}
         res[mode]["fake_size"] = pol.fake_replay_buffer.size
-        assert torch.equal(ops.mlp_transpose(pol.q_funcs.blob, S + A, 1, 2), pol.q_funcs.blob_T)
-        assert torch.equal(ops.mlp_transpose(pol.policy.blob, S, A, 1), pol.policy.blob_T)
+        assert torch.equal(ops.mlp_transpose(pol.q_funcs.blob, S + A, 1, 2, precision=mode), pol.q_funcs.blob_T)
+        assert torch.equal(ops.mlp_transpose(pol.policy.blob, S, A, 1, precision=mode), pol.policy.blob_T)
         L = pol.q_funcs.layout
-        fresh = ops.mlp_transpose(pol.target_q_funcs.blob, S + A, 1, 2).view(2, L.t_member_floats)
+        fresh = ops.mlp_transpose(pol.target_q_funcs.blob, S + A, 1, 2, precision=mode).view(2, L.t_member_floats)
         assert torch.equal(fresh[:, L.w2p:L.w2tp], pol.target_q_funcs.blob_T.view(2, L.t_member_floats)[:, L.w2p:L.w2tp])
-    assert abs(res["f32"]["fake_size"] - res["bf16x3"]["fake_size"]) <= 3      # a row at the filter / termination edge may flip
+    assert abs(res["f32"]["fake_size"] - res[split]["fake_size"]) <= 3      # a row at the filter / termination edge may flip
     for k in res["f32"]:
         if k != "fake_size":
-            np.testing.assert_allclose(res["bf16x3"][k].numpy(), res["f32"][k].numpy(), rtol=0, atol=2e-4, err_msg=k)
+            np.testing.assert_allclose(res[split][k].numpy(), res["f32"][k].numpy(), rtol=0, atol=2e-4, err_msg=k)
