@@ -128,6 +128,10 @@ struct Mlp3FwdArgs {
   long long planes_ms;               // member stride of w2_planes in bf16 elements
   float* save_d1;           // [members][rows][256] Swish derivative at the pre-activations of layers 1 / 2 (training
   float* save_d2;           // forward of the ensemble nets only: k_mlp3_fwd_train)
+  unsigned short* save_h1p; // f16 mode, instead of save_h1: the layer-1 activations as the two fp16 planes the weight-gradient GEMM
+  long long h1p_ms;         // reads ([member][2 planes][rows32 / 8][256][8], layers_bf.h PlaneSave; member stride h1p_ms and plane
+  long long h1p_plane;      // stride h1p_plane in 16-bit elements, rows32 = rows rounded up to 32) and
+  int* save_e1;             // [members][ceil(rows / 32)] the tiles' scale exponents
   int out_mode;             // 0 raw, 1 max_action*tanh
   const float* resid;       // optional: out[m][row][c] += resid[row*resid_ld + c] (shared by the members; mopo dynamics: s + f(s,a))
   int resid_ld;

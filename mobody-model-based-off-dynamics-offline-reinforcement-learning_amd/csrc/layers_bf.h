@@ -26,12 +26,24 @@ __device__ __forceinline__ void relu_mask_words(f32x16 (&y)[MT][2], uint32_t* ma
     }
 }
 
+// Optional global copy of a tile's planes for the weight-gradient GEMM (f16 mode): the SAME scaled terms that go to LDS, in
+// the layout that GEMM reads as fragments -- plane[p][row / 8][256 columns][8 rows] (a lane's A/B fragment of
+// v_mfma_f32_32x32x16_f16, eight consecutive rows of one column, is ONE 16-byte load; csrc/mlp_bwd.hip wgrad_tile_f16) --
+// plus the tile's scale exponent.  `base` points at this tile's first 8-row block of plane 0.
+struct PlaneSave {
+  short* base;               // null: no copy
+  long long plane_stride;    // 16-bit elements between planes (rows rounded up to 32, times 256)
+  int* e_out;                // this tile's scale exponent
+};
+
 // Write the planes of a wide result held in accumulators (values y, scaled by 2^e in the f16 mode) and hand every element
 // to extra(guarded, row, col, y): four consecutive rows of a lane's feature go out as one 8-byte store per plane.
 template <int MT, int PM, int TB, class Extra, class Guard>
-__device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, int e, Extra&& extra, Guard guarded) {
+__device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, int e, Extra&& extra, Guard guarded,
+                                                const PlaneSave& gs = PlaneSave{nullptr, 0, nullptr}) {
   const int lane = lane_id(), i = lane & 31, h = lane >> 5;
   const float sc = Split<PM>::F16 ? exp2i(e) : 1.f;
+  if (gs.base != nullptr && (int)threadIdx.x < TB / 32) gs.e_out[threadIdx.x] = e;      // one exponent per 32 rows
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -42,7 +54,7 @@ __device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, 
         float y4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) y4[j] = Split<PM>::F16 ? acc[mt][nt][4 * g + j] * sc : acc[mt][nt][4 * g + j];
-        planes_store4<PM, TB>(Ps, col, 8 * (MT * wave_rg() + mt) + 2 * g + h, y4);
+        planes_store4<PM, TB>(Ps, col, 8 * (MT * wave_rg() + mt) + 2 * g + h, y4, gs.base, gs.plane_stride);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           extra(guarded, 32 * (MT * wave_rg() + mt) + 8 * g + 4 * h + j, col, acc[mt][nt][4 * g + j]);
@@ -55,7 +67,8 @@ __device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, 
 template <int ACT, int MT, int PM, int TB, class Extra, class Between>
 __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* scr, const float* __restrict__ W,
                                                     const float* __restrict__ b, int Kp, WideRing& ring, Extra&& extra,
-                                                    Between&& between, uint32_t* mask, bool full, int mask_groups) {
+                                                    Between&& between, uint32_t* mask, bool full, int mask_groups,
+                                                    int rows_here = 1 << 30, const PlaneSave& gs = PlaneSave{nullptr, 0, nullptr}) {
   const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
   f32x16 acc[MT][2];
   wide_zero<MT>(acc);
@@ -69,7 +82,9 @@ __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* 
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float y = activate<ACT>(acc[mt][nt][r] + (nt ? bias1 : bias0));
+        float y = activate<ACT>(acc[mt][nt][r] + (nt ? bias1 : bias0));
+        // the global plane copy feeds a contraction over ROWS: rows past the end of the batch must be zero there
+        if (gs.base != nullptr && !full && 32 * (MT * wave_rg() + mt) + (r & 3) + 8 * (r >> 2) + 4 * (lane_id() >> 5) >= rows_here) y = 0.f;
         acc[mt][nt][r] = y;
         if constexpr (Split<PM>::F16) mx = fmaxf(mx, fabsf(y));
       }
@@ -77,8 +92,8 @@ __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* 
   lds_barrier();                                   // every wave has read the old image (and posted its maximum)
   int e = 0;
   if constexpr (Split<PM>::F16) e = f16_scale_exp(f16_tile_max_get(scr));
-  if (full) planes_from_acc<MT, PM, TB>(acc, Ps, e, extra, std::false_type{});
-  else planes_from_acc<MT, PM, TB>(acc, Ps, e, extra, std::true_type{});
+  if (full) planes_from_acc<MT, PM, TB>(acc, Ps, e, extra, std::false_type{}, gs);
+  else planes_from_acc<MT, PM, TB>(acc, Ps, e, extra, std::true_type{}, gs);
   TR(7);
   if (mask != nullptr) relu_mask_words<MT>(acc, mask, mask_groups);
   lds_barrier();

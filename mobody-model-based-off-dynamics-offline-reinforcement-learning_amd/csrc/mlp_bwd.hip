@@ -93,12 +93,13 @@ __device__ __forceinline__ float wide_mask_apply(f32x16 (&acc)[MT][2], const flo
 // 64w + 32nt + (lane&31), nt = 0,1.
 template <int MT, int PM>
 __device__ __forceinline__ void wide_store_colsum(f32x16 (&acc)[MT][2], float* Xs, float* gdst, int rows_here, int e,
-                                                  float (&cs)[2]) {
+                                                  float (&cs)[2], const PlaneSave& gs = PlaneSave{nullptr, 0, nullptr}) {
   const int lane = lane_id(), w = wave_id();
   const int i = lane & 31, hh = lane >> 5;
   cs[0] = cs[1] = 0.f;
   if constexpr (PM > 0) {
     const float sc = Split<PM>::F16 ? exp2i(e) : 1.f;
+    if (gs.base != nullptr && (int)threadIdx.x < MT) gs.e_out[threadIdx.x] = e;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -108,7 +109,7 @@ __device__ __forceinline__ void wide_store_colsum(f32x16 (&acc)[MT][2], float* X
           float y4[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) y4[j] = Split<PM>::F16 ? acc[mt][nt][4 * g + j] * sc : acc[mt][nt][4 * g + j];
-          planes_store4<PM, 32 * MT>(reinterpret_cast<char*>(Xs), 64 * w + 32 * nt + i, 8 * mt + 2 * g + hh, y4);
+          planes_store4<PM, 32 * MT>(reinterpret_cast<char*>(Xs), 64 * w + 32 * nt + i, 8 * mt + 2 * g + hh, y4, gs.base, gs.plane_stride);
         }
   }
   auto sweep = [&](auto guarded) {
@@ -268,7 +269,13 @@ __global__ __launch_bounds__(NTHREADS, (MT == 1 && MASK == 1) ? 3 : 2) void k_ml
   }
   lds_barrier();
   if constexpr (PM == 4) e2 = f16_scale_exp(f16_tile_max_get(scr));
-  wide_store_colsum<MT, PM>(acc, Xs, dz2, rows_here, e2, cs);
+  PlaneSave gs{nullptr, 0, nullptr};
+  if (PM == 4 && a.dz2p != nullptr) {              // the weight-gradient GEMM reads dz2 as the planes formed here
+    gs.base = reinterpret_cast<short*>(a.dz2p) + m * a.dz2p_ms + (row0 / 8) * (HID * 8);
+    gs.plane_stride = a.dz2p_plane;
+    gs.e_out = a.e2_out + (long long)m * cdiv(a.rows, 32) + row0 / 32;
+  }
+  wide_store_colsum<MT, PM>(acc, Xs, dz2, rows_here, e2, cs, gs);
   if (lane < 32) { dbp[HID + 64 * w + lane] = cs[0]; dbp[HID + 64 * w + 32 + lane] = cs[1]; }
   lds_barrier();
   TR(3);
@@ -600,6 +607,112 @@ __device__ __forceinline__ void wgrad_tile_bf(const WgradJob& jb, const WgradArg
   wgrad_store<MT, NT>(jb, a, acc, k0, n0, slice, m, red);
 }
 
+// "f16x2" form of the 256 x 256 job: both operands arrive PRE-SPLIT -- the two fp16 planes the forward (h1) and backward
+// (dz2) epilogues stored in fragment order, [row / 8][256][8] per plane -- so a lane's A / B fragment is ONE 16-byte load and
+// the row loop has no conversion work at all: per 16-row block 8 loads and 12 MFMAs (three products on four 32 x 32 tiles).
+// Every 32-row tile carries its own power-of-two scales (planes hold h1 * 2^eA[t], dz2 * 2^eB[t]); a wave brings its
+// blocks to one common scale U = min_t (eA[t] + eB[t]) over its rows by multiplying the B fragments with the exact factor
+// 2^(U - eA[t] - eB[t]) <= 1 (v_pk_mul_f16; a tile far below the wave's largest one underflows gracefully, its contribution
+// to the sum is below fp32 resolution anyway) and un-scales its accumulators once at the end.
+__device__ __forceinline__ void wgrad_tile_f16(const WgradJob& jb, const WgradArgs& a, int tile, int slice, int m, float* red) {
+  constexpr int MT = 2, NT = 2, TK = 64, TN = 64, RB = 16;
+  const int lane = lane_id(), w = __builtin_amdgcn_readfirstlane(wave_id());
+  const int i = lane & 31, h = lane >> 5;
+  const int tk = tile / jb.tiles_n, tn = tile - tk * jb.tiles_n;
+  const int k0 = tk * TK, n0 = tn * TN;
+  const long long r_begin = ((long long)slice * 4 + w) * a.rows_per_wave;      // multiple of 16
+  const long long r_end = min(a.rows, r_begin + a.rows_per_wave);
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int x = 0; x < MT; ++x)
+#pragma unroll
+    for (int y = 0; y < NT; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  int U = 0;
+  if (r_begin < r_end) {
+    const int nblk = (int)((r_end - r_begin + RB - 1) / RB);                   // the planes are zero beyond the batch (rows32)
+    const int* eA = a.eA + m * a.e_mstride;
+    const int* eB = a.eB + m * a.e_mstride;
+    // Lane l keeps the summed exponent of the slice's tile t0 + l (a slice has at most 64 tiles: launch_wgrad), so the row
+    // loop takes a block's scale with v_readlane instead of a memory round trip in front of its MFMAs.
+    const int t0 = (int)(r_begin >> 5), t1 = (int)((r_end - 1) >> 5);
+    const int Ev = (t0 + lane <= t1) ? eA[t0 + lane] + eB[t0 + lane] : 0x7fffffff;
+    U = Ev;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) U = min(U, __shfl_xor(U, o));
+    U = __builtin_amdgcn_readfirstlane(U);
+    // 16-byte units: plane p of a member starts at p * plane_stride / 8; fragment of block b, column c: ((r / 8 + h) * 256 + c)
+    const s16x8* pa = reinterpret_cast<const s16x8*>(jb.A) + (m * jb.a_mstride) / 8 + ((r_begin >> 3) + h) * HID + k0 + i;
+    const s16x8* pb = reinterpret_cast<const s16x8*>(jb.B) + (m * jb.b_mstride) / 8 + ((r_begin >> 3) + h) * HID + n0 + i;
+    const long long ps = a.plane_stride / 8;
+    struct Blk { s16x8 a[2][MT], b[2][NT]; int sh; };
+    auto load = [&](int b, Blk& k) {
+      const long long o = (long long)b * 2 * HID;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int x = 0; x < MT; ++x) k.a[p][x] = pa[p * ps + o + 32 * x];
+#pragma unroll
+        for (int y = 0; y < NT; ++y) k.b[p][y] = pb[p * ps + o + 32 * y];
+      }
+      const int t = (int)((r_begin + (long long)b * RB) >> 5);
+      k.sh = U - __builtin_amdgcn_readlane(Ev, t - t0);                         // <= 0
+    };
+    auto mma = [&](Blk& k) {
+      // 2^sh as a packed fp16 pair (sh >= -24 stays exact down to the smallest subnormal; below that the tile is noise)
+      const int shc = max(k.sh, -24);
+      const _Float16 f = (_Float16)__int_as_float((shc + 127) << 23);
+      s16x8 bs[2][NT];
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int y = 0; y < NT; ++y) bs[p][y] = __builtin_bit_cast(s16x8, __builtin_bit_cast(f16x8, k.b[p][y]) * f);
+#pragma unroll
+      for (int x = 0; x < MT; ++x)
+#pragma unroll
+        for (int y = 0; y < NT; ++y) {
+          acc[x][y] = split_mfma<4>(k.a[0][x], bs[1][y], acc[x][y]);          // smallest terms first
+          acc[x][y] = split_mfma<4>(k.a[1][x], bs[0][y], acc[x][y]);
+          acc[x][y] = split_mfma<4>(k.a[0][x], bs[0][y], acc[x][y]);
+        }
+    };
+    Blk b0, b1;
+    // straight-line body as in wgrad_tile: the last pass re-loads block nblk - 1, unused if nblk is even
+    load(0, b0);
+    for (int blk = 0; blk + 1 < nblk; blk += 2) {
+      load(blk + 1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load(min(blk + 2, nblk - 1), b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nblk & 1) mma(b0);
+  }
+#pragma unroll
+  for (int x = 0; x < MT; ++x)
+#pragma unroll
+    for (int y = 0; y < NT; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = ldexpf(acc[x][y][r], -U);
+  wgrad_store<MT, NT>(jb, a, acc, k0, n0, slice, m, red);
+}
+
+__global__ __launch_bounds__(NTHREADS, 2) void k_wgrad_f16(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float red[];     // [2][64][64]
+  const int id = blockIdx.x, xcd = id & 7, j = id >> 3;
+  const int sm = xcd + 8 * (j / a.tiles_total);
+  const int t = j % a.tiles_total;
+  if (sm >= a.nsplit * a.members) return;
+  const int slice = sm / a.members, m = sm - slice * a.members;
+  if (t < a.job[0].ntiles) wgrad_tile_f16(a.job[0], a, t, slice, m, red);
+  else if (t < a.job[0].ntiles + a.job[1].ntiles) wgrad_tile<1>(a.job[1], a, t - a.job[0].ntiles, slice, m, red);
+  else wgrad_tile<1>(a.job[2], a, t - a.job[0].ntiles - a.job[1].ntiles, slice, m, red);
+}
+
 template <int NPL>
 __global__ __launch_bounds__(NTHREADS, 2) void k_wgrad_bf(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float red[];     // [2][64][64]
@@ -637,7 +750,7 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
   }
   long long rpw = cdiv(a.rows, (long long)4 * a.nsplit);
   a.rows_per_wave = (rpw + 15) & ~15LL;               // whole 8- / 16-row blocks for every wave but the last one with work
-  for (int k = 0; k < 3; ++k)                         // a wave addresses its row slice through 32-bit buffer offsets
+  for (int k = (a.prec == 4 && a.eA != nullptr) ? 1 : 0; k < 3; ++k)     // a wave addresses its row slice through 32-bit buffer offsets
     if (a.rows_per_wave * (long long)std::max(a.job[k].lda, a.job[k].ldb) * 4 >= (1LL << 31))
       return fail(MOBODY_E_ARG, "launch_wgrad: row slice too large for 32-bit offsets (raise nsplit)");
   a.job[0].tiles_n = (a.job[0].nb + 63) / 64; a.job[0].ntiles = ((a.job[0].ka + 63) / 64) * a.job[0].tiles_n;
@@ -649,6 +762,18 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
   // Split-precision job 0 in every bf16 mode (the operand split costs ~6 VALU instructions per value and term; with the
   // unmasked scalar-addressed row loop that still leaves a gain: per step at c2 0.058 ms fp32 job -> 0.052 bf16x3,
   // 0.044 bf16x2); MOBODY_WGRAD_BF=0 keeps the job in fp32 (tuning aid).
+  if (a.prec == 4 && a.eA != nullptr) {               // "f16x2": job 0 on the pre-split fp16 planes
+    if (a.rows_per_wave > 2048) return fail(MOBODY_E_ARG, "launch_wgrad: more than 64 row tiles per wave slice (raise nsplit)");
+    static bool once_h = false;
+    if (!once_h) {
+      int rc = allow_big_lds(k_wgrad_f16, lds);
+      if (rc) return rc;
+      once_h = true;
+    }
+    hipLaunchKernelGGL(k_wgrad_f16, dim3(blocks), dim3(NTHREADS), lds, st, a);
+    MB_LAUNCH_OK("k_wgrad_f16");
+    return 0;
+  }
   static const int bf_force = [] { const char* e = getenv("MOBODY_WGRAD_BF"); return e ? atoi(e) : -1; }();
   const bool use_bf = bf_force == 0 ? false : a.prec != 0;
   if (use_bf && a.job[0].ka == HID && a.job[0].nb == HID && a.job[0].wide) {
@@ -746,15 +871,18 @@ __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
 int mlp3_weight_grads(const MobodyMlpLayout& L, const float* x, long long x_mstride, const float* h1, const float* h2,
                       const float* dz3, const float* dz2, const float* dz1, long long rows, int nsplit, float* slabs,
                       const float* dbp, int ntiles, float* grad, const LossFinal& loss, const AdamTarget& adam,
-                      hipStream_t st, int prec) {
+                      hipStream_t st, int prec, const int* e_h1, const int* e_dz2) {
   WgradArgs g{};
   g.prec = prec;
+  const long long rows32 = (rows + 31) & ~31LL;
+  g.eA = e_h1; g.eB = e_dz2; g.e_mstride = rows32 / 32; g.plane_stride = rows32 * HID;
   const long long slab_stride = (L.total_floats + 3) & ~3LL;
   g.rows = rows; g.slabs = slabs; g.slab_stride = slab_stride; g.out_mstride = L.member_floats;
   g.nsplit = nsplit; g.members = L.members;
   const long long hs = rows * HID;
   // dW2 = h1^T dz2
   g.job[0] = WgradJob{h1, hs, HID, HID, dz2, hs, HID, HID, L.w2, HID, HID, HID, 0, 1, 0, 0};
+  if (prec == 4 && e_h1 != nullptr) g.job[0].a_mstride = g.job[0].b_mstride = 2 * rows32 * HID;   // planes: 16-bit elements per member
   // dW1 = x^T dz1
   g.job[1] = WgradJob{x, x_mstride, L.Kp1, L.Kp1, dz1, hs, HID, HID, L.w1, HID, L.Kp1, HID, 0, 1, 0, 0};
   // dW3^T = dz3^T h2, stored transposed into W3[256][Np3]

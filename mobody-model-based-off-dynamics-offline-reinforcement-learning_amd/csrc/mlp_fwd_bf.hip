@@ -49,11 +49,17 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
   uint32_t* mask2 = a.mask2 ? a.mask2 + mtile : nullptr;
   const int mg = (rows_here + 31) / 32;
   BfRing<PM> bring;
+  PlaneSave gs{nullptr, 0, nullptr};
+  if (a.save_h1p != nullptr) {
+    gs.base = reinterpret_cast<short*>(a.save_h1p) + m * a.h1p_ms + (row0 / 8) * (HID * 8);
+    gs.plane_stride = a.h1p_plane;
+    gs.e_out = a.save_e1 + (long long)m * cdiv(a.rows, 32) + row0 / 32;
+  }
   const int e1 = wide_layer_to_planes<ACT, MT, PM, TB>(Xs, Ps, scr, w1, a.b1 + m * a.sb1, a.Kp1, ring,
                                      [=](auto guarded, int row, int col, float y) {
                                        if (h1 != nullptr && (!decltype(guarded)::value || row < rows_here)) h1[row * HID + col] = y;
                                      },
-                                     [&] { bf_prefetch<PM>(w2b, bring); }, mask1, full, mg);
+                                     [&] { bf_prefetch<PM>(w2b, bring); }, mask1, full, mg, rows_here, gs);
   TR(2);
   auto save_h2 = [=](auto guarded, int row, int col, float y) {
     if (h2 != nullptr && (!decltype(guarded)::value || row < rows_here)) h2[row * HID + col] = y;

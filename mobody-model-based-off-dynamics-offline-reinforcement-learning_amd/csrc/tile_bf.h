@@ -88,10 +88,13 @@ __device__ __forceinline__ f32x16 split_mfma(s16x8 a, s16x8 b, f32x16 c) {
 // ---- power-of-two tile scales of the f16 mode ---------------------------------------------------------------------------
 // exponent e such that m * 2^e lies in [2^13, 2^14) (fp16 overflows at 2^16; the residual term of anything above
 // 2^-3 of the tile maximum stays a normal fp16 number, smaller values degrade gracefully to an absolute error of 2^-39 of
-// the maximum); 0 for m = 0, denormal, Inf or NaN (a non-finite tile is garbage either way and NaNs propagate through the MFMA)
+// the maximum).  An all-zero (or denormal) tile gets the LARGEST exponent, 100: its planes are zero whatever the scale, and
+// the weight-gradient GEMM, which brings the tiles of a row slice to their smallest exponent, must not let an empty tile
+// set that common scale.  Inf / NaN: 0 (a non-finite tile is garbage either way and NaNs propagate through the MFMA).
 __device__ __forceinline__ int f16_scale_exp(float m) {
   const int eb = (__float_as_int(m) >> 23) & 0xff;
-  if (eb == 0 || eb == 255) return 0;
+  if (eb == 0) return 100;
+  if (eb == 255) return 0;
   const int e = 13 - (eb - 127);
   return e > 100 ? 100 : e;
 }
@@ -125,8 +128,11 @@ template <int TB>
 constexpr int plane_bytes() { return HID * TB * 2; }
 
 // Store the NPL terms of four consecutive rows (rows 4c .. 4c+3 of the tile, chunk c) of feature k: one ds_write_b64 per plane.
+// gbase (optional): the same terms also go to global planes laid out [row / 8][256][8] (plane stride gstride elements),
+// gbase pointing at the tile's first 8-row block: chunk c is the half (c & 1) of block c >> 1.
 template <int PM, int TB>
-__device__ __forceinline__ void planes_store4(char* Ps, int k, int c, const float (&y)[4]) {
+__device__ __forceinline__ void planes_store4(char* Ps, int k, int c, const float (&y)[4], short* gbase = nullptr,
+                                              long long gstride = 0) {
   constexpr int NPL = Split<PM>::NPL;
   short t[4][NPL];
 #pragma unroll
@@ -136,6 +142,7 @@ __device__ __forceinline__ void planes_store4(char* Ps, int k, int c, const floa
   for (int p = 0; p < NPL; ++p) {
     s16x4 v; v[0] = t[0][p]; v[1] = t[1][p]; v[2] = t[2][p]; v[3] = t[3][p];
     *reinterpret_cast<s16x4*>(Ps + p * plane_bytes<TB>() + off) = v;
+    if (gbase != nullptr) *reinterpret_cast<s16x4*>(gbase + p * gstride + ((long long)(c >> 1) * HID + k) * 8 + 4 * (c & 1)) = v;
   }
 }
 

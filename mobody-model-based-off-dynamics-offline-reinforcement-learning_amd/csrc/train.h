@@ -64,6 +64,10 @@ struct Mlp3BwdArgs {
   long long rows;
   float* dz2;              // [members][rows][256] or null (not needed when only dx is wanted)
   float* dz1;
+  unsigned short* dz2p;    // f16 mode, instead of dz2: its two fp16 planes in the weight-gradient GEMM's fragment layout
+  long long dz2p_ms;       // ([member][2][rows32 / 8][256][8]; member / plane strides in 16-bit elements, layers_bf.h PlaneSave)
+  long long dz2p_plane;
+  int* e2_out;             // [members][ceil(rows / 32)] the tiles' scale exponents of dz2p
   float* dbp;              // [tiles][members][512 + Np3] bias-gradient partials: db1 | db2 | db3
   float* dx;               // [members][rows][dx_n] input gradient columns [dx_c0, dx_c0 + dx_n)  (DX only)
   int dx_c0, dx_n;
@@ -79,6 +83,11 @@ struct WgradJob {
   int tiles_n, ntiles;                                 // filled by launch_wgrad
 };
 struct WgradArgs {
+  // prec 4 ("f16x2"): job 0's operands are NOT fp32 rows but the planes the forward / backward epilogues saved
+  // (job[0].A = h1 planes, job[0].B = dz2 planes: [member][2][rows32 / 8][256][8] fp16, a_mstride / b_mstride in 16-bit
+  // elements) together with the 32-row tiles' scale exponents eA / eB ([member][tiles])
+  const int *eA, *eB;
+  long long e_mstride, plane_stride;                   // tiles per member; 16-bit elements between the two planes
   WgradJob job[3];                                     // job 0: 64x64 wave tiles, jobs 1-2: 32x64
   long long rows, rows_per_wave;
   float* slabs; long long slab_stride, out_mstride;    // partial slab s = slabs + s*slab_stride (gradient-blob layout)
@@ -214,10 +223,11 @@ struct GradReduceArgs {
   AdamTarget adam;      // on = 0: none
 };
 int launch_grad_reduce(const GradReduceArgs& a, hipStream_t st);
+// prec 4: h1 / dz2 point at the saved fp16 planes and e_h1 / e_dz2 at their tile exponents (else null)
 int mlp3_weight_grads(const MobodyMlpLayout& L, const float* x, long long x_mstride, const float* h1, const float* h2,
                       const float* dz3, const float* dz2, const float* dz1, long long rows, int nsplit, float* slabs,
                       const float* dbp, int ntiles, float* grad, const LossFinal& loss, const AdamTarget& adam,
-                      hipStream_t st, int prec = 0);
+                      hipStream_t st, int prec = 0, const int* e_h1 = nullptr, const int* e_dz2 = nullptr);
 
 // split-K factor (workgroups along the row dimension) used for a batch of `rows`: 24 output tiles x nsplit x members
 // workgroups should reach ~3 per CU (768), so a one-member net splits twice as fine as a twin net
@@ -226,6 +236,7 @@ inline int wgrad_nsplit(long long rows, int members) {
   long long s = rows / (members == 1 ? 128 : 256);
   if (s < 1) s = 1;
   if (s > cap) s = cap;
+  while (rows > 2048LL * 4 * s) s *= 2;             // a wave's row slice spans at most 64 tiles of 32 rows (wgrad_tile_f16)
   return (int)s;
 }
 

@@ -18,6 +18,7 @@ namespace mobody {
 // ------------------------------------------------------------------------------------------------
 struct TrainWs {
   uint32_t *mq1, *mq2, *ma1, *ma2;      // ReLU sign words of the twin-Q / actor hidden layers
+  int *eh1q, *eh1a, *edz2;              // f16 mode: scale exponents of the 32-row tiles of the h1 / dz2 planes
   float *pin;            // pi(s') of the critic phase (pi holds pi(s) for the actor phase)
   float *pi, *qt, *q, *qb, *xq, *h1q, *h2q, *xa, *h1a, *h2a, *dz3q, *dz2, *dz1, *dz3a, *dxa, *bcw, *dbp, *slabs, *lossp;
   long long total;
@@ -31,6 +32,7 @@ static int carve(const MobodyTrainDims& d, float* base, TrainWs& w) {
   rc = mobody_mlp_layout(d.S, d.A, 1, &w.La);
   if (rc) return rc;
   const long long N = d.N, Nt = d.Nt;
+  const long long N32 = (N + 31) & ~31LL;             // h1 / dz2 hold fp16 planes of whole 32-row tiles in the f16 mode (same bytes)
   long long off = 0;
   auto take = [&](long long n) { float* p = base ? base + off : nullptr; off += (n + 3) & ~3LL; return p; };
   w.pi = take(N * d.A);
@@ -39,16 +41,17 @@ static int carve(const MobodyTrainDims& d, float* base, TrainWs& w) {
   w.q = take(2 * N);
   w.qb = take(2 * Nt);
   w.xq = take(N * w.Lq.Kp1);
-  w.h1q = take(2 * N * HID);
+  w.h1q = take(2 * N32 * HID);
   w.h2q = take(2 * N * HID);
   w.xa = take(N * w.La.Kp1);
-  w.h1a = take(N * HID);
+  w.h1a = take(N32 * HID);
   w.h2a = take(N * HID);
   const long long mw = cdiv(N, 32) * HID;
   w.mq1 = (uint32_t*)take(2 * mw); w.mq2 = (uint32_t*)take(2 * mw);
   w.ma1 = (uint32_t*)take(mw); w.ma2 = (uint32_t*)take(mw);
+  w.eh1q = (int*)take(2 * (N32 / 32)); w.eh1a = (int*)take(N32 / 32); w.edz2 = (int*)take(2 * (N32 / 32));
   w.dz3q = take(2 * N * w.Lq.Np3);
-  w.dz2 = take(2 * N * HID);
+  w.dz2 = take(2 * N32 * HID);
   w.dz1 = take(2 * N * HID);
   w.dz3a = take(N * w.La.Np3);
   w.dxa = take(2 * N * d.A);
@@ -196,10 +199,17 @@ __global__ __launch_bounds__(256) void k_mlp_transpose(MobodyMlpLayout L, const 
 // ------------------------------------------------------------------------------------------------
 // helpers to launch the fused MLP pieces on a packed blob
 // ------------------------------------------------------------------------------------------------
+// e1 != null (f16 mode): sh1 receives the layer-1 activations as fp16 planes + tile exponents instead of fp32 rows
 static Mlp3FwdArgs fwd_args(const float* blob, const MobodyMlpLayout& L, const float* s0, int n0, const float* s1, int n1,
                             long long rows, float* out, int out_mode, float max_action, float* sx, float* sh1,
-                            float* sh2, uint32_t* m1 = nullptr, uint32_t* m2 = nullptr, const float* blob_T = nullptr) {
+                            float* sh2, uint32_t* m1 = nullptr, uint32_t* m2 = nullptr, const float* blob_T = nullptr,
+                            int* e1 = nullptr) {
   Mlp3FwdArgs a{};
+  if (e1 != nullptr && sh1 != nullptr) {
+    const long long r32 = (rows + 31) & ~31LL;
+    a.save_h1p = reinterpret_cast<unsigned short*>(sh1); a.h1p_plane = r32 * HID; a.h1p_ms = 2 * r32 * HID; a.save_e1 = e1;
+    sh1 = nullptr;
+  }
   if (blob_T != nullptr) {                          // split-precision modes stream W2's bf16 planes from the T blob
     a.w2_planes = reinterpret_cast<const unsigned short*>(blob_T + L.w2p);
     a.planes_ms = 2 * L.t_member_floats;
@@ -236,15 +246,21 @@ static int check_prec(const MobodyHyper* h, const char* who, bool have_planes) {
 // weight gradients of one packed MLP: one merged split-K launch + the deterministic reduction
 static int weight_grads(const MobodyMlpLayout& L, const float* x, const float* h1, const float* h2, const float* dz3,
                         const float* dz2, const float* dz1, long long rows, const TrainWs& w, float* grad,
-                        const LossFinal& loss, const AdamTarget& adam, hipStream_t st, int prec = 0) {
+                        const LossFinal& loss, const AdamTarget& adam, hipStream_t st, int prec = 0, const int* e_h1 = nullptr) {
   return mlp3_weight_grads(L, x, 0, h1, h2, dz3, dz2, dz1, rows, L.members == 1 ? w.nsplit_a : w.nsplit_q, w.slabs, w.dbp,
-                           w.ntiles, grad, loss, adam, st, prec);
+                           w.ntiles, grad, loss, adam, st, prec, prec == 4 ? e_h1 : nullptr, prec == 4 ? w.edz2 : nullptr);
 }
 
+// e2 != null (f16 mode): dz2 receives fp16 planes + tile exponents instead of fp32 rows
 static Mlp3BwdArgs bwd_args(const MobodyMlpLayout& L, const float* blob_T, const float* dz3, const float* h1,
                             const float* h2, long long rows, float* dz2, float* dz1, float* dbp,
-                            const uint32_t* m1 = nullptr, const uint32_t* m2 = nullptr, int prec = 0) {
+                            const uint32_t* m1 = nullptr, const uint32_t* m2 = nullptr, int prec = 0, int* e2 = nullptr) {
   Mlp3BwdArgs b{};
+  if (prec == 4 && e2 != nullptr && dz2 != nullptr) {
+    const long long r32 = (rows + 31) & ~31LL;
+    b.dz2p = reinterpret_cast<unsigned short*>(dz2); b.dz2p_plane = r32 * HID; b.dz2p_ms = 2 * r32 * HID; b.e2_out = e2;
+    dz2 = nullptr;
+  }
   b.prec = prec; b.w2t_planes = reinterpret_cast<const unsigned short*>(blob_T + L.w2tp); b.planes_ms = 2 * L.t_member_floats;
   b.dz3 = dz3; b.h1 = h1; b.h2 = h2; b.m1 = m1; b.m2 = m2; b.wt = blob_T; b.t_mstride = L.t_member_floats;
   b.w3t = L.w3t; b.w2t = L.w2t; b.w1t = L.w1t; b.Np3 = L.Np3; b.Np1t = L.Np1t; b.rows = rows;
@@ -288,7 +304,8 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
   const long long N = d->N;
   const int S = d->S, A = d->A;
   // online twin-Q(s, a), activations kept for the backward (:196), together with a' = pi(s') (:191) in one launch
-  const Mlp3FwdArgs fq = fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q, w.mq1, w.mq2, qT);
+  const Mlp3FwdArgs fq = fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q, w.mq1, w.mq2, qT,
+                                  prec == 4 ? w.eh1q : nullptr);
   if (q_next == nullptr) {
     rc = fwd_pair(fq, 2, fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pin, 1, h->max_action, nullptr, nullptr, nullptr, nullptr, nullptr, aT), 1, prec, st);
     // target twin-Q(s', a') (:192) -- and, when the caller asks for it, pi(s) of the coming actor phase in the same
@@ -296,7 +313,8 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
     // merged one is 3.75 (the actor phase then opens with Q(s_t,a_t) alone: exactly 2 per CU)
     const Mlp3FwdArgs ft = fwd_args(qtarg_blob, w.Lq, next_state, S, w.pin, A, N, w.qt, 0, 1.f, nullptr, nullptr, nullptr, nullptr, nullptr, tT);
     if (!rc && policy_forward)
-      rc = fwd_pair(ft, 2, fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2, aT), 1, prec, st);
+      rc = fwd_pair(ft, 2, fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2, aT,
+                                    prec == 4 ? w.eh1a : nullptr), 1, prec, st);
     else if (!rc)
       rc = fwd_one(ft, 2, prec, st);
   } else {
@@ -305,14 +323,14 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
   if (rc) return rc;
   const float invNg = 1.f / (float)d->N_global;
   // TD error -> dz3 in the backward's prologue (mobody.py:190-207), then dz2, dz1 and the bias partials
-  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp, w.mq1, w.mq2, prec);
+  Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp, w.mq1, w.mq2, prec, w.edz2);
   bq.seed.mode = 1; bq.seed.q = w.q; bq.seed.qt = w.qt; bq.seed.qnext = q_next; bq.seed.r = reward; bq.seed.nd = not_done;
   bq.seed.gamma = h->gamma; bq.seed.inv_ng = invNg; bq.seed.dz3_out = w.dz3q; bq.seed.lossp = w.lossp;
   rc = launch_mlp3_bwd(bq, 2, false, w.tile_rows, st);
   if (rc) return rc;
   LossFinal lf{};                                  // q_loss = mse(q1,y)+mse(q2,y), local share of the global mean
   lf.kind = 1; lf.nparts = 2 * w.ntiles; lf.scale = invNg; lf.parts = w.lossp; lf.out = loss_out;
-  return weight_grads(w.Lq, w.xq, w.h1q, w.h2q, w.dz3q, w.dz2, w.dz1, N, w, grad_q, lf, adam, st, prec);
+  return weight_grads(w.Lq, w.xq, w.h1q, w.h2q, w.dz3q, w.dz2, w.dz1, N, w, grad_q, lf, adam, st, prec, w.eh1q);
 }
 
 extern "C" int mobody_critic_step(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
@@ -371,7 +389,8 @@ extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper*
     if (policy_ready)
       rc = fwd_one(fb, 2, prec, st);
     else
-      rc = fwd_pair(fb, 2, fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2, aT), 1, prec, st);
+      rc = fwd_pair(fb, 2, fwd_args(actor_blob, w.La, state, S, nullptr, 0, N, w.pi, 1, h->max_action, w.xa, w.h1a, w.h2a, w.ma1, w.ma2, aT,
+                                    prec == 4 ? w.eh1a : nullptr), 1, prec, st);
     if (!rc) rc = fwd_one(fp, 2, prec, st);
   }
   if (rc) return rc;
@@ -407,14 +426,14 @@ static int actor_backward_impl(const MobodyTrainDims* d, const MobodyHyper* h, c
   rc = launch_mlp3_bwd(bq, 2, true, w.tile_rows, st);
   if (rc) return rc;
   // actor: d(pre-tanh) from both members' dx and the BC term in the prologue, then the actor's own backward
-  Mlp3BwdArgs ba = bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp, w.ma1, w.ma2, h->precision);
+  Mlp3BwdArgs ba = bwd_args(w.La, actor_blob_T, w.dz3a, w.h1a, w.h2a, N, w.dz2, w.dz1, w.dbp, w.ma1, w.ma2, h->precision, w.edz2);
   ba.seed.mode = 3; ba.seed.ar = ra; ba.seed.dz3_out = w.dz3a; ba.seed.lossp = w.lossp;
   rc = launch_mlp3_bwd(ba, 1, false, w.tile_rows, st);
   if (rc) return rc;
   LossFinal lf{};                                  // loss_out[0] = p_w*mean(-q) + bc_coef*L_BC, [1] = L_BC (local shares)
   lf.kind = 2; lf.nparts = w.ntiles; lf.scale_q = h->scale_q; lf.weight = h->weight; lf.bc_coef = h->bc_coef;
   lf.ng = (float)ra.Ng; lf.ntg_a = (float)ra.Ntg * (float)ra.A; lf.parts = w.lossp; lf.stats = stats; lf.out = loss_out;
-  return weight_grads(w.La, w.xa, w.h1a, w.h2a, w.dz3a, w.dz2, w.dz1, N, w, grad_actor, lf, adam, st, h->precision);
+  return weight_grads(w.La, w.xa, w.h1a, w.h2a, w.dz3a, w.dz2, w.dz1, N, w, grad_actor, lf, adam, st, h->precision, w.eh1a);
 }
 
 extern "C" int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
