@@ -64,9 +64,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   if constexpr (PM > 0) {
     const s16x8* pz = reinterpret_cast<const s16x8*>(a.planes + dyn_planes_off(0, e));
     const int ez = wide_layer_to_planes<ACT_SWISH, MT, PMX, TB>(Xs, Ps, scr, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1),
-                                                                a.L.layer[MOBODY_DL_ZS1].Kp, ring, NoExtra{},
-                                                                [&] { bf_prefetch<PMX>(pz, bring); }, nullptr, false, 0);
-    bf_layer<ACT_SWISH, MT, PMX, TB>(Xs, Ps, ez, pz, Bp(MOBODY_DL_ZS2), bring, NoExtra{}, [] {}, nullptr, false, 0);
+                                                                a.L.layer[MOBODY_DL_ZS1].Kp, ring,
+                                                                [&] { bf_prefetch<PMX>(pz, bring); });
+    bf_layer<ACT_SWISH, MT, PMX, TB>(Xs, Ps, ez, pz, Bp(MOBODY_DL_ZS2), bring, [] {});
   } else {
     wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_ZS1), Bp(MOBODY_DL_ZS1), a.L.layer[MOBODY_DL_ZS1].Kp, ring, NoExtra{},
                               [&] { wide_prefetch(Wp(MOBODY_DL_ZS2), HID, ring); });
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   const s16x8* pt = PM > 0 ? reinterpret_cast<const s16x8*>(a.planes + dyn_planes_off(1, e)) : nullptr;
   int et = 0;
   if constexpr (PM > 0)
-    et = wide_layer_to_planes<ACT_SWISH, MT, PMX, TB>(Xs, Ps, scr, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, ring, NoExtra{},
-                                                      [&] { bf_prefetch<PMX>(pt, bring); }, nullptr, false, 0);
+    et = wide_layer_to_planes<ACT_SWISH, MT, PMX, TB>(Xs, Ps, scr, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, ring,
+                                                      [&] { bf_prefetch<PMX>(pt, bring); });
   else
     wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR1), Bp(MOBODY_DL_TR1), 16, ring, NoExtra{},
                               [&] { wide_prefetch(Wp(MOBODY_DL_TR2), HID, ring); });
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_dyn_fwd(DynFwdArgs a) {
   float* mean = a.mean + ((long long)e * a.B + row0) * S;
   // transition2 at the requested precision; `between` runs after its last MFMA (the output layer's early requests)
   auto layer_tr2 = [&](auto&& between) {
-    if constexpr (PM > 0) bf_layer<ACT_SWISH, MT, PMX, TB>(Xs, Ps, et, pt, Bp(MOBODY_DL_TR2), bring, NoExtra{}, between, nullptr, false, 0);
+    if constexpr (PM > 0) bf_layer<ACT_SWISH, MT, PMX, TB>(Xs, Ps, et, pt, Bp(MOBODY_DL_TR2), bring, between);
     else wide_layer<ACT_SWISH, MT>(Xs, Wp(MOBODY_DL_TR2), Bp(MOBODY_DL_TR2), HID, ring, NoExtra{}, between);
   };
   if constexpr (NT3 > 0) {

@@ -36,39 +36,50 @@ struct PlaneSave {
   int* e_out;                // this tile's scale exponent
 };
 
-// Write the planes of a wide result held in accumulators (values y, scaled by 2^e in the f16 mode) and hand every element
-// to extra(guarded, row, col, y): four consecutive rows of a lane's feature go out as one 8-byte store per plane.
-template <int MT, int PM, int TB, class Extra, class Guard>
-__device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, int e, Extra&& extra, Guard guarded,
-                                                const PlaneSave& gs = PlaneSave{nullptr, 0, nullptr}) {
+// Row-major fp32 copy of a wide result held in accumulators to global memory (tile base dst, leading dimension 256): 32
+// coalesced dword stores per lane as ONE branch-free burst when the tile is full; the per-element row guard (v_cmp + exec
+// save / restore around every store) only on the batch's last, ragged tile.
+template <int MT>
+__device__ __forceinline__ void wide_store_rows(f32x16 (&acc)[MT][2], float* dst, bool full, int rows_here) {
+  if (full) wide_foreach<MT>(acc, [&](int row, int col, float y) { dst[row * HID + col] = y; });
+  else wide_foreach<MT>(acc, [&](int row, int col, float y) { if (row < rows_here) dst[row * HID + col] = y; });
+}
+
+// Write the planes of a wide result held in accumulators (values y, scaled by 2^e in the f16 mode): four consecutive rows
+// of a lane's feature go out as one 8-byte store per plane (and, optionally, one more to the global copy gs).
+template <int MT, int PM, int TB>
+__device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, int e, const PlaneSave& gs) {
   const int lane = lane_id(), i = lane & 31, h = lane >> 5;
   const float sc = Split<PM>::F16 ? exp2i(e) : 1.f;
   if (gs.base != nullptr && (int)threadIdx.x < TB / 32) gs.e_out[threadIdx.x] = e;      // one exponent per 32 rows
+  auto sweep = [&](short* gbase) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = 64 * wave_col() + 32 * nt + i;
+      for (int nt = 0; nt < 2; ++nt) {
+        const int col = 64 * wave_col() + 32 * nt + i;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float y4[4];
+        for (int g = 0; g < 4; ++g) {
+          float y4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y4[j] = Split<PM>::F16 ? acc[mt][nt][4 * g + j] * sc : acc[mt][nt][4 * g + j];
-        planes_store4<PM, TB>(Ps, col, 8 * (MT * wave_rg() + mt) + 2 * g + h, y4, gs.base, gs.plane_stride);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          extra(guarded, 32 * (MT * wave_rg() + mt) + 8 * g + 4 * h + j, col, acc[mt][nt][4 * g + j]);
+          for (int j = 0; j < 4; ++j) y4[j] = Split<PM>::F16 ? acc[mt][nt][4 * g + j] * sc : acc[mt][nt][4 * g + j];
+          planes_store4<PM, TB>(Ps, col, 8 * (MT * wave_rg() + mt) + 2 * g + h, y4, gbase, gs.plane_stride);
+        }
       }
-    }
+  };
+  if (gs.base != nullptr) sweep(gs.base);          // (wave uniform: two straight-line variants instead of a test per store)
+  else sweep(nullptr);
 }
 
 // fp32 layer whose output goes to planes instead of the fp32 image.  Returns the tile's scale exponent (planes hold
-// y * 2^e; 0 outside the f16 mode).  `scr`: 8 floats of LDS for the tile maximum (f16 mode).
-template <int ACT, int MT, int PM, int TB, class Extra, class Between>
+// y * 2^e; 0 outside the f16 mode).  `scr`: 8 floats of LDS for the tile maximum (f16 mode).  Optional copies of the
+// activations: gsave (fp32 rows, this tile's base) and gs (fp16 planes for the weight-gradient GEMM); optional sign words.
+template <int ACT, int MT, int PM, int TB, class Between>
 __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* scr, const float* __restrict__ W,
-                                                    const float* __restrict__ b, int Kp, WideRing& ring, Extra&& extra,
-                                                    Between&& between, uint32_t* mask, bool full, int mask_groups,
-                                                    int rows_here = 1 << 30, const PlaneSave& gs = PlaneSave{nullptr, 0, nullptr}) {
+                                                    const float* __restrict__ b, int Kp, WideRing& ring, Between&& between,
+                                                    uint32_t* mask = nullptr, bool full = true, int mask_groups = 0,
+                                                    int rows_here = 1 << 30, float* gsave = nullptr,
+                                                    const PlaneSave& gs = PlaneSave{nullptr, 0, nullptr}) {
   const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
   f32x16 acc[MT][2];
   wide_zero<MT>(acc);
@@ -82,36 +93,45 @@ __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* 
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float y = activate<ACT>(acc[mt][nt][r] + (nt ? bias1 : bias0));
-        // the global plane copy feeds a contraction over ROWS: rows past the end of the batch must be zero there
-        if (gs.base != nullptr && !full && 32 * (MT * wave_rg() + mt) + (r & 3) + 8 * (r >> 2) + 4 * (lane_id() >> 5) >= rows_here) y = 0.f;
+        const float y = activate<ACT>(acc[mt][nt][r] + (nt ? bias1 : bias0));
         acc[mt][nt][r] = y;
         if constexpr (Split<PM>::F16) mx = fmaxf(mx, fabsf(y));
       }
+  // the global plane copy feeds a contraction over ROWS: rows past the end of the batch must be zero there
+  // (wave uniform and only on the ragged last tile; their activations are act(bias), harmless for the tile maximum)
+  if (gs.base != nullptr && !full) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (32 * (MT * wave_rg() + mt) + (r & 3) + 8 * (r >> 2) + 4 * (lane_id() >> 5) >= rows_here) acc[mt][nt][r] = 0.f;
+  }
   if constexpr (Split<PM>::F16) f16_tile_max_put(mx, scr);
   lds_barrier();                                   // every wave has read the old image (and posted its maximum)
   int e = 0;
   if constexpr (Split<PM>::F16) e = f16_scale_exp(f16_tile_max_get(scr));
-  if (full) planes_from_acc<MT, PM, TB>(acc, Ps, e, extra, std::false_type{}, gs);
-  else planes_from_acc<MT, PM, TB>(acc, Ps, e, extra, std::true_type{}, gs);
+  planes_from_acc<MT, PM, TB>(acc, Ps, e, gs);
+  if (gsave != nullptr) wide_store_rows<MT>(acc, gsave, full, rows_here);
   TR(7);
   if (mask != nullptr) relu_mask_words<MT>(acc, mask, mask_groups);
   lds_barrier();
   return e;
 }
 
-// split-precision layer: planes (scaled by 2^e_in in the f16 mode) -> fp32 image
-template <int ACT, int MT, int PM, int TB, class Extra, class Between>
+// split-precision layer: planes (scaled by 2^e_in in the f16 mode) -> fp32 image (+ optional fp32 copy gsave, sign words)
+template <int ACT, int MT, int PM, int TB, class Between>
 __device__ __forceinline__ void bf_layer(float* Xs, const char* Ps, int e_in, const s16x8* __restrict__ Wb,
-                                         const float* __restrict__ b, BfRing<PM>& ring, Extra&& extra, Between&& between,
-                                         uint32_t* mask, bool full, int mask_groups) {
+                                         const float* __restrict__ b, BfRing<PM>& ring, Between&& between,
+                                         uint32_t* mask = nullptr, bool full = true, int mask_groups = 0,
+                                         int rows_here = 1 << 30, float* gsave = nullptr) {
   const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
   f32x16 acc[MT][2];
   wide_zero<MT>(acc);
   bf_gemm<MT, PM, TB>(Ps, Wb, acc, ring);
   TR(3);
   between();
-  lds_barrier();
   const float inv = Split<PM>::F16 ? exp2i(-(e_in + F16_WSHIFT)) : 1.f;     // exact: both scales are powers of two
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -122,14 +142,9 @@ __device__ __forceinline__ void bf_layer(float* Xs, const char* Ps, int e_in, co
         const float bias = nt ? bias1 : bias0;
         acc[mt][nt][r] = activate<ACT>(Split<PM>::F16 ? fmaf(acc[mt][nt][r], inv, bias) : acc[mt][nt][r] + bias);
       }
-  auto body = [&](auto guarded) {
-    wide_foreach<MT>(acc, [&](int row, int col, float y) {
-      Xs[row * LDX + col] = y;
-      extra(guarded, row, col, y);
-    });
-  };
-  if (full) body(std::false_type{});
-  else body(std::true_type{});
+  lds_barrier();                                   // every wave has read the planes
+  wide_foreach<MT>(acc, [&](int row, int col, float y) { Xs[row * LDX + col] = y; });
+  if (gsave != nullptr) wide_store_rows<MT>(acc, gsave, full, rows_here);
   if (mask != nullptr) relu_mask_words<MT>(acc, mask, mask_groups);
   lds_barrier();
 }

@@ -112,23 +112,17 @@ __device__ __forceinline__ void wide_store_colsum(f32x16 (&acc)[MT][2], float* X
           planes_store4<PM, 32 * MT>(reinterpret_cast<char*>(Xs), 64 * w + 32 * nt + i, 8 * mt + 2 * g + hh, y4, gs.base, gs.plane_stride);
         }
   }
-  auto sweep = [&](auto guarded) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const int col = 64 * w + 32 * nt + i;
-          const float dz = acc[mt][nt][r];
-          if constexpr (PM == 0) Xs[row * LDX + col] = dz;
-          if (gdst != nullptr && (!decltype(guarded)::value || row < rows_here)) gdst[row * HID + col] = dz;
-          cs[nt] += dz;
-        }
-  };
-  if (rows_here == 32 * MT) sweep(std::false_type{});
-  else sweep(std::true_type{});
+      for (int r = 0; r < 16; ++r) {
+        const float dz = acc[mt][nt][r];
+        if constexpr (PM == 0) Xs[(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh) * LDX + 64 * w + 32 * nt + i] = dz;
+        cs[nt] += dz;
+      }
+  if (gdst != nullptr) wide_store_rows<MT>(acc, gdst, rows_here == 32 * MT, rows_here);      // one branch-free burst on full tiles
   cs[0] += __shfl_xor(cs[0], 32);
   cs[1] += __shfl_xor(cs[1], 32);
 }

@@ -8,6 +8,9 @@
 #include "common.h"
 #include "layers_bf.h"
 
+#ifndef FWD_F16_WAVES
+#define FWD_F16_WAVES 2
+#endif
 namespace mobody {
 
 template <int ACT, int PM, int RG, int NT>
@@ -56,14 +59,8 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
     gs.e_out = a.save_e1 + (long long)m * cdiv(a.rows, 32) + row0 / 32;
   }
   const int e1 = wide_layer_to_planes<ACT, MT, PM, TB>(Xs, Ps, scr, w1, a.b1 + m * a.sb1, a.Kp1, ring,
-                                     [=](auto guarded, int row, int col, float y) {
-                                       if (h1 != nullptr && (!decltype(guarded)::value || row < rows_here)) h1[row * HID + col] = y;
-                                     },
-                                     [&] { bf_prefetch<PM>(w2b, bring); }, mask1, full, mg, rows_here, gs);
+                                                       [&] { bf_prefetch<PM>(w2b, bring); }, mask1, full, mg, rows_here, h1, gs);
   TR(2);
-  auto save_h2 = [=](auto guarded, int row, int col, float y) {
-    if (h2 != nullptr && (!decltype(guarded)::value || row < rows_here)) h2[row * HID + col] = y;
-  };
   float* out = a.out + m * a.out_mstride + row0 * a.out_ld;
   auto emit = [&](int row, int col, float v, float bias) {
     if (row < rows_here && col < a.nout) {
@@ -77,14 +74,14 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
     NarrowRegs<NT> br;
     const int mycol = threadIdx.x % (16 * NT);
     float bias;
-    bf_layer<ACT, MT, PM, TB>(Xs, Ps, e1, w2b, a.b2 + m * a.sb2, bring, save_h2, [&] {
+    bf_layer<ACT, MT, PM, TB>(Xs, Ps, e1, w2b, a.b2 + m * a.sb2, bring, [&] {
       narrow_prefetch<NT>(w3, 16 * NT, br);
       bias = b3[mycol < a.nout ? mycol : 0];
-    }, mask2, full, mg);
+    }, mask2, full, mg, rows_here, h2);
     TR(4);
     narrow_run<TB / 16, NT>(Xs, br, [&](int row, int col, float v) { emit(row, col, v, bias); });
   } else {
-    bf_layer<ACT, MT, PM, TB>(Xs, Ps, e1, w2b, a.b2 + m * a.sb2, bring, save_h2, [] {}, mask2, full, mg);
+    bf_layer<ACT, MT, PM, TB>(Xs, Ps, e1, w2b, a.b2 + m * a.sb2, bring, [] {}, mask2, full, mg, rows_here, h2);
     narrow_layer(Xs, w3, HID, a.Np3, [&](int row, int col, float v) { emit(row, col, v, b3[col < a.nout ? col : 0]); }, TB);
   }
   TR(5);
@@ -92,7 +89,7 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
 
 // one or two independent networks per launch (blockIdx.y < members_a -> net a), as k_mlp3_fwd2
 template <int ACT, int PM, int RG, int NT>
-__global__ __launch_bounds__(NTHREADS * RG, 2) void k_mlp3_fwd_bf(Mlp3FwdArgs a, Mlp3FwdArgs b, int members_a) {
+__global__ __launch_bounds__(NTHREADS * RG, (PM == 4 && RG == 1) ? FWD_F16_WAVES : 2) void k_mlp3_fwd_bf(Mlp3FwdArgs a, Mlp3FwdArgs b, int members_a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   const bool second = (int)blockIdx.y >= members_a;
   const Mlp3FwdArgs s = second ? b : a;

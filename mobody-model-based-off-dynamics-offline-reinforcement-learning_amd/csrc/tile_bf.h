@@ -33,20 +33,23 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(8))) short s16x8;       // one MFMA A/B fragment as raw 16-bit lanes (either format)
 typedef __attribute__((ext_vector_type(4))) short s16x4;
-constexpr int BF_RING = 3;                     // k16 steps of weight fragments in flight
 constexpr long long BF_PLANE = 32LL * HID;     // s16x8 units per weight plane ([K/8 = 32][256])
 constexpr int F16_WSHIFT = 8;                  // "f16x2" weight planes hold w * 2^8 (|w| < 255; residual terms stay normal down to |w| ~ 5e-4)
 
+#ifndef SPLIT_RING
+#define SPLIT_RING 3
+#endif
 template <int PM>
 struct Split {
   static_assert(PM >= 1 && PM <= 4, "precision mode 1..4");
   static constexpr int NPL = PM == 4 ? 2 : PM;
   static constexpr bool F16 = PM == 4;
+  static constexpr int RING = SPLIT_RING;        // k16 steps of weight fragments in flight
 };
 constexpr int split_planes(int pm) { return pm == 4 ? 2 : pm; }
 
 template <int PM>
-struct BfRing { s16x8 r[BF_RING][Split<PM>::NPL][2]; };
+struct BfRing { s16x8 r[Split<PM>::RING][Split<PM>::NPL][2]; };
 
 // element index (in 16-bit units) of weight (k, n) inside plane p of a member's plane block
 __host__ __device__ inline long long bf_plane_idx(int p, int k, int n) { return (((long long)p * 32 + (k >> 3)) * HID + n) * 8 + (k & 7); }
@@ -158,7 +161,7 @@ __device__ __forceinline__ void bf_ldb(const s16x8* __restrict__ Wb, int s, s16x
 template <int PM>
 __device__ __forceinline__ void bf_prefetch(const s16x8* __restrict__ Wb, BfRing<PM>& ring) {
 #pragma unroll
-  for (int j = 0; j < BF_RING - 1; ++j) bf_ldb<PM>(Wb, j, ring.r[j]);
+  for (int j = 0; j < Split<PM>::RING - 1; ++j) bf_ldb<PM>(Wb, j, ring.r[j]);
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -166,7 +169,7 @@ __device__ __forceinline__ void bf_prefetch(const s16x8* __restrict__ Wb, BfRing
 template <int MT, int PM, int TB>
 __device__ __forceinline__ void bf_gemm(const char* __restrict__ Ps, const s16x8* __restrict__ Wb, f32x16 (&acc)[MT][2],
                                         BfRing<PM>& ring) {
-  constexpr int R = BF_RING, NPL = Split<PM>::NPL;
+  constexpr int R = Split<PM>::RING, NPL = Split<PM>::NPL;
   using lds_s16x4 = __attribute__((address_space(3))) s16x4;
   const int lane = lane_id(), g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, h = lane >> 5;
   // transposed read of k-step s, half j, tile m: lane 4q + pp of a 16-lane group supplies the address of k-row

@@ -14,7 +14,7 @@ lib = _lib.load()
 S, A = 17, 6
 pa, pq, _ = gu.policy_params(1, S, A)
 qb = packing.pack_mlp(pq, S + A, 1, dev, prefixes=["network1.", "network2."])
-qT = ops.mlp_transpose(qb, S + A, 1, 2)
+qT = {p: ops.mlp_transpose(qb, S + A, 1, 2, precision=p) for p in (3, 4)}
 L = _lib.mlp_layout(S + A, 1, 2)
 
 
@@ -38,13 +38,13 @@ for rows in [int(x) for x in sys.argv[1:]] or (2560, 10240, 40960):
     sx = torch.empty(rows, L.Kp1, device=dev); sh1 = torch.empty(2, rows, 256, device=dev); sh2 = torch.empty(2, rows, 256, device=dev)
 
     def fwd(prec, save):
-        rc = lib.mobody_mlp3_forward(ptr(qb), ptr(qT), prec, S + A, 1, 2, ptr(s), S, ptr(a), A, rows, 0, 1.0, ptr(out),
+        rc = lib.mobody_mlp3_forward(ptr(qb), ptr(qT[4 if prec == 4 else 3]), prec, S + A, 1, 2, ptr(s), S, ptr(a), A, rows, 0, 1.0, ptr(out),
                                      ptr(sx if save else None), ptr(sh1 if save else None), ptr(sh2 if save else None), _lib.cur_stream())
         assert rc == 0, lib.mobody_last_error()
 
     fwd(0, False); torch.cuda.synchronize(); ref = out.clone()
     line = f"rows {rows:6d}:"
-    for prec, name in enumerate(("f32", "bf16", "bf16x2", "bf16x3")):
+    for prec, name in enumerate(("f32", "bf16", "bf16x2", "bf16x3", "f16x2")):
         fwd(prec, False); torch.cuda.synchronize()
         err = float((out - ref).abs().max() / ref.abs().max())
         line += f" | {name} {timeit(lambda: fwd(prec, False)):6.1f} us, saving {timeit(lambda: fwd(prec, True)):6.1f} us, err {err:.1e}"
