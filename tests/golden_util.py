@@ -85,3 +85,19 @@ def mopo_params_for(g, tag):
     p["za_src3.bias"][:, 0, 0] += np.float32(-0.35 if tag == "walker" else -0.3)
     assert abs(gi.checksum(p) - float(g["wsum"])) <= 1e-9 * abs(float(g["wsum"])), "weight generator drifted from the fixture"
     return p
+
+
+def dyn_kw(blob, S, A, mode):
+    """planes= / precision= keyword arguments of ops.dyn_forward / dyn_step / rollout for MFMA mode `mode`."""
+    from mobody_amd import ops
+    if mode in (None, "f32", 0):
+        return {}
+    return dict(planes=ops.dyn_planes(blob, S, A, precision=mode), precision=mode)
+
+
+def mlp_kw(blob, in_dim, out_dim, members, mode):
+    """blob_T= / precision= keyword arguments of ops.mlp3_forward for MFMA mode `mode`."""
+    from mobody_amd import ops
+    if mode in (None, "f32", 0):
+        return {}
+    return dict(blob_T=ops.mlp_transpose(blob, in_dim, out_dim, members, precision=mode), precision=mode)

@@ -28,21 +28,22 @@ def dev():
 
 
 @pytest.mark.parametrize("tag", ["walker", "ant", "pen"])
-def test_dyn_forward_and_step_vs_golden(tag, dev):
+def test_dyn_forward_and_step_vs_golden(tag, mfma, dev):
     from mobody_amd import ops, packing, _lib
     g = gu.load(f"g234_dynamics_{tag}")
     S, A = int(g["S"]), int(g["A"])
     p = gu.dyn_params_for(g)
     blob = packing.pack_dynamics(p, S, A, dev)
+    kw = gu.dyn_kw(blob, S, A, mfma)
     obs, act = torch.from_numpy(g["obs"]).to(dev), torch.from_numpy(g["act"]).to(dev)
-    close(ops.dyn_forward(blob, S, A, obs, act, True), g["mean_trg"])
-    close(ops.dyn_forward(blob, S, A, obs, act, False), g["mean_src"])
+    close(ops.dyn_forward(blob, S, A, obs, act, True, **kw), g["mean_trg"])
+    close(ops.dyn_forward(blob, S, A, obs, act, False, **kw), g["mean_src"])
     task = _lib.TERM_IDS[O.resolve_task(str(g["task"]))]
     for up in (1, 0):
         for ut in (1, 0):
             k = f"step_p{up}_t{ut}_"
             r = ops.dyn_step(blob, S, A, task, obs, act, noise=g[k + "eps"], elite_idx=g[k + "idx"], penalty_coef=0.1,
-                             use_penalty=bool(up), use_trg=bool(ut), want_mean=True)
+                             use_penalty=bool(up), use_trg=bool(ut), want_mean=True, **kw)
             close(r["mean"], g[k + "samples"])
             close(r["next_obs"], g[k + "next_obs"])
             close(r["penalty"], g[k + "penalty"])
@@ -54,7 +55,7 @@ def test_dyn_forward_and_step_vs_golden(tag, dev):
 
 
 @pytest.mark.parametrize("B", [1, 63, 64, 65, 200])
-def test_dyn_step_ragged_batches_vs_oracle(B, dev):
+def test_dyn_step_ragged_batches_vs_oracle(B, mfma, dev):
     from mobody_amd import ops, packing
     S, A = 17, 6
     p = gu.gi.dyn_params(7, S, A)
@@ -66,7 +67,7 @@ def test_dyn_step_ragged_batches_vs_oracle(B, dev):
     with torch.no_grad():
         want = O.dyn_step(O.to_torch(p), obs, act, eps, idx, "walker2d-medium-v2", penalty_coef=0.25)
     got = ops.dyn_step(blob, S, A, 4, torch.from_numpy(obs).to(dev), torch.from_numpy(act).to(dev), noise=eps,
-                       elite_idx=idx, penalty_coef=0.25)
+                       elite_idx=idx, penalty_coef=0.25, **gu.dyn_kw(blob, S, A, mfma))
     for k in ("next_obs", "reward", "penalty", "raw_reward"):
         close(got[k], want[k])
     assert (got["terminal"].cpu().numpy().astype(bool) == want["terminal"]).all()

@@ -55,7 +55,7 @@ def dev():
 
 
 @pytest.mark.parametrize("name", list(CONFIGS))
-def test_train_step_full_size_vs_oracle(name, dev):
+def test_train_step_full_size_vs_oracle(name, mfma, dev):
     S, A, N, Nt = CONFIGS[name]
     cfg = gu.policy_cfg(S, A)
     pa, pq, pv = gu.policy_params(91, S, A)
@@ -104,7 +104,7 @@ def test_full_size_gradients_as_close_to_fp64_as_the_reference_is(dev, monkeypat
 
 
 @pytest.mark.parametrize("name", ["C2", "C4"])
-def test_train_step_full_size_is_deterministic_and_shards_linearly(name, dev):
+def test_train_step_full_size_is_deterministic_and_shards_linearly(name, mfma, dev):
     from mobody_amd import ops
     S, A, N, Nt = CONFIGS[name]
     cfg = gu.policy_cfg(S, A)
@@ -144,7 +144,7 @@ def test_train_step_full_size_is_deterministic_and_shards_linearly(name, dev):
 
 
 @pytest.mark.parametrize("S,A,task,tid", [(17, 6, "walker2d-medium-v2", 4), (111, 8, "ant-medium-v2", 3)])
-def test_dyn_step_refresh_size_vs_oracle(S, A, task, tid, dev):
+def test_dyn_step_refresh_size_vs_oracle(S, A, task, tid, mfma, dev):
     """One ensemble step over the 52 000 init states of a refresh (mobody.py:441-475), device-side draws."""
     from mobody_amd import ops, packing
     B = 52000
@@ -153,10 +153,11 @@ def test_dyn_step_refresh_size_vs_oracle(S, A, task, tid, dev):
     blob = packing.pack_dynamics(p, S, A, dev)
     rng = np.random.default_rng(8)
     obs = gu.gi.walker_like_obs(rng, B, S); act = rng.uniform(-1, 1, (B, A)).astype(np.float32)
+    kw = gu.dyn_kw(blob, S, A, mfma)
     got = ops.dyn_step(blob, S, A, tid, torch.from_numpy(obs).to(dev), torch.from_numpy(act).to(dev), seed=21, call=2,
-                       penalty_coef=0.1)
+                       penalty_coef=0.1, **kw)
     again = ops.dyn_step(blob, S, A, tid, torch.from_numpy(obs).to(dev), torch.from_numpy(act).to(dev), seed=21, call=2,
-                         penalty_coef=0.1)
+                         penalty_coef=0.1, **kw)
     for k in ("next_obs", "reward", "penalty", "terminal"):
         assert torch.equal(got[k], again[k]), k
     z = ops.rng_normal(21, 1, 2, B * S, dev).cpu().numpy().reshape(B, S)
@@ -175,7 +176,7 @@ def test_dyn_step_refresh_size_vs_oracle(S, A, task, tid, dev):
     assert 0 < flags.sum() < B                                   # both outcomes occur in this sample
 
 
-def test_rollout_refresh_horizon5_into_million_row_buffer(dev):
+def test_rollout_refresh_horizon5_into_million_row_buffer(mfma, dev):
     """C3: 52 000 init states, horizon 5, penalty filter, appended to a 1 000 000-row fake buffer."""
     from mobody_amd import ops
     from mobody_amd.algo.offline_offline.mobody import MOBODY

@@ -75,7 +75,7 @@ def test_call_algo_contract(dev):
 
 
 @pytest.mark.parametrize("tag", ["h1", "h5", "h3_nopen"])
-def test_mirror_rollout_vs_reference_golden(tag, dev):
+def test_mirror_rollout_vs_reference_golden(tag, mfma, dev):
     from mobody_amd.algo.offline_offline.mobody import MOBODY
     g = gu.load(f"g6_rollout_{tag}")
     S, A = int(g["S"]), int(g["A"])
@@ -108,7 +108,7 @@ class FixedRows:
 
 
 @pytest.mark.parametrize("tag", ["default", "noqw", "noscale", "nofake", "bc05", "par", "adv"])
-def test_mirror_train_vs_reference_golden(tag, dev):
+def test_mirror_train_vs_reference_golden(tag, mfma, dev):
     from mobody_amd.algo.offline_offline.mobody import MOBODY
     from test_hip_train import params_close
     g = gu.load(f"g7_train_{tag}")
@@ -141,7 +141,7 @@ def test_mirror_train_vs_reference_golden(tag, dev):
     assert pol.total_it == 3
 
 
-def test_device_rollout_into_fake_buffer_matches_oracle(dev):
+def test_device_rollout_into_fake_buffer_matches_oracle(mfma, dev):
     """rng='device': alive-mask rollout + fused filtered append == oracle rollout fed with the device's draws."""
     from mobody_amd import ops
     from mobody_amd.algo.offline_offline.mobody import MOBODY
@@ -252,7 +252,7 @@ def test_first_train_call_refreshes_fake_buffer_and_checkpoints_round_trip(dev, 
     pol.dynamics.load(str(d))
 
 
-def test_graph_replay_matches_eager_steps(dev):
+def test_graph_replay_matches_eager_steps(mfma, dev):
     """config['graph']=1: the captured steady-state step (device-side RNG call / Adam step counters) produces the
     same parameters as eager execution fed with the same device draws."""
     from mobody_amd import synthetic, ops
@@ -295,7 +295,7 @@ def test_graph_replay_matches_eager_steps(dev):
     close(g.target_q_funcs.blob, e.target_q_funcs.blob, rtol=1e-6, atol=1e-8)
 
 
-def test_dara_classifier_vs_reference_golden(dev):
+def test_dara_classifier_vs_reference_golden(mfma, dev):
     """G9: classifier probabilities, the log-ratio penalty and one update_classifier step (loss + gradients)
     with the reference's recorded permutation and input noise."""
     from mobody_amd import ops
@@ -437,7 +437,7 @@ def _refresh_policy(g, cfg, dev, monkeypatch):
 
 
 @pytest.mark.parametrize("tag", ["default", "fromsrc"])
-def test_mirror_refresh_step_vs_reference_golden(tag, dev, monkeypatch):
+def test_mirror_refresh_step_vs_reference_golden(tag, mfma, dev, monkeypatch):
     """The FIRST train() call (total_it 0 -> 1) against the reference (fixture g11): refresh order
     src rollout -> add -> trg rollout -> add -> (s,a) relabel with strict '<' -> [rollout_from_src with a classifier
     step and the DARA reward term], the NumPy index/elite stream consumed in the reference's order, the fake ring's
@@ -504,7 +504,7 @@ def test_mirror_relabel_filter_is_strict(dev, monkeypatch):
     assert pol.fake_replay_buffer.size == int((pen2 <= thr2).sum())
 
 
-def test_dara_penalize_fake_vs_reference_golden(dev):
+def test_dara_penalize_fake_vs_reference_golden(mfma, dev):
     """penalize_fake=1 (fixture g9_dara_penfake): the mirror's own update_classifier (no rows/labels supplied) must draw
     src(bs), tar(bs), fake(bs), tar(2bs) in the reference's order (mobody.py:147-154) and train on src (label 0) |
     fake (label 1) rows -- the reference's labels cover 2*bs rows only, so its target rows never reach the classifier."""
@@ -543,7 +543,7 @@ def test_dara_penalize_fake_vs_reference_golden(dev):
         params_close(gu.sub(v.cpu().numpy()), g["cls_p::" + k], cfg["actor_lr"], max_frac=0.5)
 
 
-def test_reference_written_checkpoint_loads_and_continues(dev):
+def test_reference_written_checkpoint_loads_and_continues(mfma, dev):
     """tests/golden/ckpt_ref/model_* were written by the REFERENCE's MOBODY.save after two train() steps (make_golden.g16).
     The mirror loads them (weights_only=True), exposes the same tensors, and its next train() step equals the step the
     reference takes from the same files (fixture g16: losses, post-step parameters) -- which pins the optimizer state
@@ -619,7 +619,7 @@ def test_writer_scalars_on_the_reference_cadence(dev, tmp_path):
     close(torch.tensor(got["train/q_behavior"][1]), torch.minimum(q12[0], q12[1]).mean().cpu(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "f16x2", "bf16x3"])
 def test_mirror_tracks_the_reference_over_thirty_steps(mode, dev):
     """g17: 30 reference train() steps on rotating preset batches.  The mirror's losses follow the reference's step by step
     and the final actor / twin-Q / target parameters agree -- in exact fp32 and in the bench's default bf16x3 mode."""

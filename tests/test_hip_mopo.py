@@ -16,7 +16,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "f16x2", "bf16x3"])
 @pytest.mark.parametrize("tag", ["walker", "ant"])
 def test_mopo_forward_and_step_vs_reference_golden(tag, mode, dev):
     g = gu.load(f"g18_mopo_{tag}")

@@ -48,7 +48,7 @@ from mobody_amd.engine import Engine  # noqa: E402  (the C-ABI driver ships with
 
 
 @pytest.mark.parametrize("tag", ["default", "noqw", "noscale", "nofake", "bc05"])
-def test_train_step_vs_reference_golden(tag, dev):
+def test_train_step_vs_reference_golden(tag, mfma, dev):
     g = gu.load(f"g7_train_{tag}")
     S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
     cfg = gu.policy_cfg(S, A, **gu.G7_VARIANTS[tag])
@@ -71,7 +71,7 @@ def test_train_step_vs_reference_golden(tag, dev):
 
 
 @pytest.mark.parametrize("S,A,N,Nt", [(17, 6, 640, 512), (17, 6, 333, 200), (111, 8, 192, 128), (45, 24, 130, 65)])
-def test_train_step_vs_oracle_shapes(S, A, N, Nt, dev):
+def test_train_step_vs_oracle_shapes(S, A, N, Nt, mfma, dev):
     cfg = gu.policy_cfg(S, A)
     pa, pq, pv = gu.policy_params(77, S, A)
     batch = gu.gi.batch(5, N, S, A)
@@ -90,7 +90,7 @@ def test_train_step_vs_oracle_shapes(S, A, N, Nt, dev):
             params_close(v, params[k], cfg["critic_lr"])
 
 
-def test_train_step_without_true_rows_runs(dev):
+def test_train_step_without_true_rows_runs(mfma, dev):
     """Nt = 0 (no BC rows): the reference would average an empty tensor (NaN); the kernels define L_BC = 0."""
     S, A = 17, 6
     cfg = gu.policy_cfg(S, A)
@@ -99,7 +99,7 @@ def test_train_step_without_true_rows_runs(dev):
     assert np.isfinite(out["q_loss"]) and np.isfinite(out["pi_loss"]) and out["bc_loss"] == 0.0
 
 
-def test_data_parallel_shards_sum_to_full_batch(dev):
+def test_data_parallel_shards_sum_to_full_batch(mfma, dev):
     """N-GPU == 1-GPU by construction: run two half batches with N_global = N and sum the gradient blobs."""
     from mobody_amd import ops
     S, A, N, Nt = 17, 6, 256, 192
@@ -168,7 +168,7 @@ def test_adam_polyak_kernel(dev):
 
 
 @pytest.mark.parametrize("S,A,N,Nt", [(17, 6, 640, 512), (45, 24, 130, 65)])
-def test_fused_update_is_bit_identical_to_step_plus_adam(S, A, N, Nt, dev):
+def test_fused_update_is_bit_identical_to_step_plus_adam(S, A, N, Nt, mfma, dev):
     """mobody_critic_update / mobody_actor_update (Adam + Polyak inside the gradient reduction) vs the separate
     gradient + mobody_adam_polyak calls: same parameters, moments, target and transposed blobs, bit for bit."""
     from mobody_amd import ops
@@ -190,7 +190,7 @@ def test_fused_update_is_bit_identical_to_step_plus_adam(S, A, N, Nt, dev):
             assert torch.equal(getattr(ref, name), getattr(fus, name)), (step, name)
 
 
-def test_policy_forward_riding_with_the_target_q_launch_is_bit_identical(dev):
+def test_policy_forward_riding_with_the_target_q_launch_is_bit_identical(mfma, dev):
     """mobody_critic_step(policy_forward=1) + mobody_actor_forward(policy_ready=1) == the default placement of pi(s)."""
     from mobody_amd import ops
     S, A, N, Nt = 17, 6, 333, 200
