@@ -239,8 +239,9 @@ int mobody_gather_batch_rng(const MobodyBufferView* bufs, const int64_t* counts,
 /* Append the rows with keep[i] != 0 (NULL = all), in order, to the ring `ring` of `cap` rows (written through the
  * view's pointers) at *ptr_size (device int64[2] = {ptr, size}), reproducing add_batch's single-wrap arithmetic
  * (utils.py:43-92); not_done = 1 - terminal; the row-interleaved ring also gets its row padding zeroed.
- * `scan_ws` needs (M + 1040) int32.  Two launches: a block scan whose last block commits the new {ptr, size}, and the
- * row scatter. */
+ * `scan_ws` needs (M + 1040) int32 whose FIRST EIGHT must be zero on entry (zero the workspace once when allocating it;
+ * every call leaves them zero: they hold the scan's arrival ticket, and a memset launch per append would cost more than
+ * a short append itself).  Two launches: a block scan whose last block commits the new {ptr, size}, and the row scatter. */
 int mobody_ring_append(const MobodyBufferView* ring, int64_t cap, int64_t* ptr_size, int S, int A, const float* obs,
                        const float* act, const float* next_obs, const float* reward, const uint8_t* terminal,
                        const uint8_t* keep, int64_t M, int32_t* scan_ws, void* stream);

@@ -539,6 +539,8 @@ extern "C" int mobody_rollout(const float* dyn_blob, const float* dyn_planes, co
   RolloutWs w;
   rollout_carve(S, A, B, workspace, w);
   hipStream_t st = as_stream(stream);
+  // the appends' arrival ticket (first words of the scan region) has to start at zero; every append leaves it at zero
+  if (hipMemsetAsync(w.scan, 0, 8 * sizeof(int32_t), st) != hipSuccess) return fail(MOBODY_E_LAUNCH, "mobody_rollout: memset failed");
   const float* obs = init_obs;
   for (int t = 0; t < H; ++t) {
     float* nxt = w.obs[t & 1];

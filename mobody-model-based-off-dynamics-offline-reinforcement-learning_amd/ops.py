@@ -273,13 +273,18 @@ def gather_batch(buffers, indices, S, A, out=None):
     return out
 
 
+_scan_ws = {}
+
+
 def ring_append(buf, cap, ptr_size, S, A, obs, act, next_obs, reward, terminal, keep=None):
     """buf = RingView or (state, action, next_state, reward, not_done) ring tensors; ptr_size int64[2] device tensor."""
     M = obs.shape[0]
     if M == 0:
         return
     dev = obs.device
-    scan = torch.empty(M + 1040, dtype=torch.int32, device=dev)
+    scan = _scan_ws.get(dev)
+    if scan is None or scan.numel() < M + 1040:      # zeroed once: the append keeps its ticket words at zero itself
+        scan = _scan_ws[dev] = torch.zeros(max(M + 1040, 2 * (scan.numel() if scan is not None else 0)), dtype=torch.int32, device=dev)
     check(load().mobody_ring_append(C.byref(buffer_view(buf)), cap, ptr(ptr_size), S, A, ptr(obs), ptr(act), ptr(next_obs),
                                     ptr(reward), ptr(terminal), ptr(keep), M, ptr(scan), cur_stream()),
           "mobody_ring_append")
