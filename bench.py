@@ -6,8 +6,8 @@ rollout_len 1, batch_size 4096 per GPU -> every `MOBODY.train()` step consumes N
 transitions (4096 source + 4096 target + 2048 model-generated rows) already resident in HBM:
 replay gather -> twin-Q TD update (+Adam, Polyak) -> Q-scaled actor + Q-weighted-BC update (+Adam).
 The model-rollout refresh of the reference (50 000 + 2 000 init states x rollout_len + 50 000 relabels every 5000
-steps, mobody.py:441-475) is inside the timed region at the reference's cadence: K timed steps are followed by a
-refresh of K/5000 of that size (same code path, scaled row counts), so `ms_per_step` is the amortised cost of a step.
+steps, mobody.py:441-475) is timed once at FULL size right after the K timed steps (between barriers of its own) and
+charged at the reference's cadence: `ms_per_step` = K-step time / K + refresh time / 5000.
 
   value  = minibatch transitions consumed per second by the K timed train() steps, summed over ranks (weak scaling:
            every rank draws its own minibatch; gradients and the two actor statistics are all-reduced over RCCL)
@@ -16,7 +16,10 @@ refresh of K/5000 of that size (same code path, scaled row counts), so `ms_per_s
 
 `--gpus N` without a torch.distributed launcher starts its N ranks itself (children are spawned before the parent
 touches the GPU); under `python -m torch.distributed.run` the ranks come from the environment.
-Other configs (`--config c1|c3|c4|c5`) are the shapes of BASELINE.json configs[0], [2], [3], [4].
+Other configs (`--config c1|c3|c4|c5`) are the shapes of BASELINE.json configs[0], [2], [3], [4]; `--penalty par` runs the
+CLI's default reward shaping (one ensemble step on the source rows inside every train() step, mobody.py:428-434);
+`--config pretrain` measures the step BEFORE the hot path, dynamics pre-training (MOBODYEnsembleDynamics.learn, 256 rows x 7
+members per optimizer step, mobody_dynamics.py:594-653), with its own JSON line.
 """
 import argparse
 import ctypes as C
@@ -33,7 +36,8 @@ if ROOT not in sys.path:
 
 PEAK_F32_TFLOPS = 157.3          # MI355X dense fp32 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 / fp16 MFMA peak
+REFRESH_EVERY = 5000             # steps between two fake-buffer refreshes (mobody.py:441)
 FAMILIES = ["k_mlp3_fwd", "k_mlp3_bwd", "k_wgrad", "k_dyn_fwd"]
 CONFIGS = {   # BASELINE.json configs[i] -> shapes (per GPU)
     "c1": dict(S=17, A=6, bs=256, H=1, task="walker2d-medium-v2", penalty_type="none",
@@ -68,22 +72,34 @@ def train_flops(S, A, N, Nt):
 
 
 def wide_flops(S, A, N, Nt):
-    """The part of each family's FLOPs that sits in 256 x 256 GEMMs -- what the split-precision modes move to the bf16 core
-    (forward: one per network pass; backward: dz2 W2^T, one per network pass; weight gradients: none, they stay fp32)."""
-    return {"k_mlp3_fwd": 2.0 * 65536 * (8 * N + 2 * Nt), "k_mlp3_bwd": 2.0 * 65536 * 5 * N, "k_wgrad": 0.0}
+    """The part of each family's FLOPs that sits in 256 x 256 GEMMs -- what the split-precision modes move to the 16-bit MFMA
+    core (forward: one per network pass; backward: dz2 W2^T, one per network pass; weight gradients: the dW2 = h1^T dz2
+    job of the three nets with gradients)."""
+    return {"k_mlp3_fwd": 2.0 * 65536 * (8 * N + 2 * Nt), "k_mlp3_bwd": 2.0 * 65536 * 5 * N, "k_wgrad": 2.0 * 65536 * 3 * N}
 
 
 NPROD = {"f32": 0, "bf16": 1, "bf16x2": 3, "bf16x3": 6, "f16x2": 3}
 
 
 def effective_peak(total_flops, wide, mfma):
-    """MFMA roofline of a kernel whose instruction mix is part exact fp32 MFMA, part bf16 MFMA with NPROD products per
-    fp32 product: the time both pipes need at their dense peaks (157.3 TF fp32-input, 2.5 PF bf16; MI355X_MICROARCH.md),
+    """MFMA roofline of a kernel whose instruction mix is part exact fp32 MFMA, part 16-bit (bf16 / fp16) MFMA with NPROD
+    products per fp32 product: the time both pipes need at their dense peaks (157.3 TF fp32-input, 2.5 PF bf16 = fp16; MI355X_MICROARCH.md),
     expressed as fp32-equivalent TFLOP/s of the kernel's ALGORITHMIC flops."""
     if NPROD[mfma] == 0:
         return PEAK_F32_TFLOPS
     t_min = (total_flops - wide) / (PEAK_F32_TFLOPS * 1e12) + wide * NPROD[mfma] / (PEAK_BF16_TFLOPS * 1e12)
     return total_flops / t_min / 1e12
+
+
+def src_fingerprint():
+    """sha1 over the kernel sources and this file: ties a committed PMC summary to the build it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    pk = os.path.join(ROOT, "mobody-model-based-off-dynamics-offline-reinforcement-learning_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(pk, "*.hip")) + glob.glob(os.path.join(pk, "*.h"))) + [os.path.join(ROOT, "include", "mobody_hip.h")]:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -158,19 +174,12 @@ def build(dev, c, graph, mfma="f32", buffers=None):
     return pol, src, tar, cfg
 
 
-def scaled_refresh(pol, src, tar, bs, steps):
-    """The fake-buffer refresh at the reference's cadence: `steps`/5000 of its 50 000 / 2 000 init states (and relabels),
-    through the product's own `_refresh`."""
+def full_refresh(pol, src, tar, bs):
+    """One fake-buffer refresh at the reference's FULL size (50 000 source + 2 000 target init states x rollout_len, then
+    the 50 000 (s, a) relabels; mobody.py:441-475) through the product's own `_refresh`.  Returns the rows it rolled."""
     from mobody_amd.algo.offline_offline import mobody as M
-    n_s, n_t = max(1, math.ceil(50000 * steps / 5000)), max(1, math.ceil(2000 * steps / 5000))
-    old = (M.REFRESH_SRC, M.REFRESH_TAR)
-    M.REFRESH_SRC, M.REFRESH_TAR = n_s, n_t
-    try:
-        pol._refresh(src, tar, bs)
-    finally:
-        M.REFRESH_SRC, M.REFRESH_TAR = old
-    H = pol.config["src_rollout_length"]
-    return n_s * H + n_t * pol.config["trg_rollout_length"] + n_s
+    pol._refresh(src, tar, bs)
+    return M.REFRESH_SRC * pol.config["src_rollout_length"] + M.REFRESH_TAR * pol.config["trg_rollout_length"] + M.REFRESH_SRC
 
 
 def prof_pass(pol, src, tar, bs, steps):
@@ -316,18 +325,109 @@ def cpu_baseline(c, cfg):
                 legs=legs)
 
 
+# ------------------------------------------------------------------------------------------------ dynamics pre-training
+def pretrain_flops(S, A, b):
+    """Useful FLOPs of one learn() optimizer step (b rows x 7 members): forward MACs of the three big nets are state encoder
+    2x, transition decoder 4x, reward head 2x per row; forward + backward = 3x the forward."""
+    enc = S * 256 + 65536 + 256 * 32
+    dec = 16 * 256 + 65536 + 256 * S
+    rw = (2 * S + A) * 256 + 65536 + 512
+    return 2.0 * 3.0 * 7 * b * (2 * enc + 4 * dec + 2 * rw)
+
+
+def bench_pretrain(args, dev, world, rank):
+    """`--config pretrain`: optimizer steps per second of MOBODYEnsembleDynamics.learn (mobody_dynamics.py:594-653) at the
+    reference's batch (256 rows x 7 members), walker2d shapes, device-Philox noise, the mirror's HIP-graph replay of the
+    22-launch step; K timed steps between barriers.  Single GPU (the data-parallel form shards the batch rows)."""
+    import numpy as np
+    import torch
+    from mobody_amd import _lib, engine, synthetic
+    from mobody_amd.algo.dynamics.mobody_dynamics import MOBODYEnsembleDynamics
+    from mobody_amd.algo.dynamics.mobody_module import MOBODYModule
+    from mobody_amd.algo.mb_utils.terminal_funs import get_termination_fn
+    assert world == 1, "--config pretrain is a single-GPU measurement"
+    S, A, b, task = 17, 6, args.batch_size or 256, "walker2d-medium-v2"
+    steps, warm = args.steps, max(args.warmup, 3)
+    cfg = engine.default_config(S, A, no_vae=0, inverse_sep_reward_loss=0, train_together=0, train_with_src_threshold=1, dynamics_lr=1e-3)
+    m = MOBODYModule(S, A, 256, 7, 5, device=dev, config=cfg)
+    dyn = MOBODYEnsembleDynamics(cfg, m, None, None, get_termination_fn(task), penalty_coef=0.1, rng="device", seed=1)
+    g = torch.Generator().manual_seed(0)
+    mu = torch.from_numpy(synthetic.alive_mean(task, S))
+    n = 200000
+    data = [(mu + 0.1 * torch.randn(n, S, generator=g)).to(dev), (torch.rand(n, A, generator=g) * 2 - 1).to(dev),
+            (mu + 0.1 * torch.randn(n, S, generator=g)).to(dev), torch.randn(n, 1, generator=g).to(dev)]
+    idx = torch.randint(n, (7, steps * b), generator=g).to(device=dev, dtype=torch.int32).contiguous()
+    dyn._learn_indexed(True, data, idx[:, :warm * b].contiguous(), b)
+    dyn._learn_indexed(True, data, idx, b)                # captures the graph of this index matrix
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = dyn._learn_indexed(True, data, idx, b)        # K optimizer steps (graph replays)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # per-family times of the same step, eager (event pairs are not part of a captured graph)
+    lib = _lib.load()
+    dyn.train_graph = 0
+    k = min(steps, 50)
+    _lib.check(lib.mobody_prof_begin(k * 64), "prof_begin")
+    dyn._learn_indexed(True, data, idx[:, :k * b].contiguous(), b)
+    ms = (C.c_double * 8)(); cnt = (C.c_int64 * 8)()
+    _lib.check(lib.mobody_prof_end(ms, cnt, 8), "prof_end")
+    fam = {FAMILIES[i]: dict(ms_per_step=ms[i] / k, launches_per_step=cnt[i] / k) for i in range(3)}
+    fl = pretrain_flops(S, A, b)
+    dom = max(fam, key=lambda f: fam[f]["ms_per_step"])
+    share = {"k_mlp3_fwd": 1.0 / 3.0, "k_mlp3_bwd": 1.0 / 3.0, "k_wgrad": 1.0 / 3.0}[dom]     # fwd : dX : dW = 1 : 1 : 1
+    d = fam[dom]
+    per_launch = fl * share / max(d["launches_per_step"], 1)
+    avg_ms = d["ms_per_step"] / max(d["launches_per_step"], 1)
+    roofline = dict(kernel=dom, bound="mfma", achieved=per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
+                    peak=PEAK_F32_TFLOPS, unit="TFLOP/s", traffic=None, avg_launch_ms=avg_ms,
+                    launches_per_step=d["launches_per_step"], flops_per_launch=per_launch,
+                    peak_note="dense fp32-input MFMA peak (the pre-training kernels run exact fp32 MFMA)",
+                    traffic_note="null: no PMC pass for this configuration")
+    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    out = {"metric": "dynamics pre-training optimizer steps/sec (MOBODYEnsembleDynamics.learn, the step before the hot path)",
+           "value": steps / dt, "unit": "optimizer steps/s", "n_gpus": 1, "steps": steps, "warmup": warm,
+           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": {"workload": f"pretrain: walker2d shapes (S={S} A={A}), {b} rows x 7 members per optimizer step, target-domain batches, "
+                                  "device-Philox reparameterisation noise, HIP-graph replay", "name": "pretrain", "rows_per_step": 7 * b,
+                      "parallelism": "dp1", "hip_graph": True},
+           "samples_per_sec": steps * b * 7 / dt, "useful_tflops": fl * steps / dt / 1e12,
+           "frac_f32_mfma_peak_whole_step": fl * steps / dt / (PEAK_F32_TFLOPS * 1e12),
+           "roofline": roofline, "kernels": fam, "mean_losses": list(stats)}
+    if not args.no_cpu_baseline:
+        from oracle import mobody_oracle as O
+        threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        torch.set_num_threads(threads)
+        rng = np.random.default_rng(0)
+        st = O.DynTrainState({k_: v.cpu().numpy() for k_, v in m.state_dict().items()})
+        rows = [x[:7 * b].reshape(7, b, -1).cpu().numpy() for x in data]
+        nz = [rng.standard_normal((7, b, 16)).astype(np.float32) for _ in range(6)] + [rng.standard_normal((7, b, S)).astype(np.float32)]
+        O.dyn_learn_step(st, *rows, nz, True)
+        tc = time.time(); kk = 0
+        while time.time() - tc < 10.0 or kk < 3:
+            O.dyn_learn_step(st, *rows, nz, True); kk += 1
+        rate = kk / (time.time() - tc)
+        out["cpu_baseline"] = dict(value=rate, unit="optimizer steps/s", cores=threads, kind="port", cpu_model=cpu_model(),
+                                   sample=f"{kk} oracle learn steps (torch CPU fp32 autograd, {threads} threads) at the same shapes")
+        out["gpu_over_cpu"] = out["value"] / rate
+    print(json.dumps(out))
+    sys.stdout.flush()
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + ["pretrain"])
+    ap.add_argument("--penalty", default=None, choices=["none", "par", "dara"], help="override the config's penalty_type ('par' = the CLI default)")
     ap.add_argument("--batch_size", type=int, default=None, help="override the config's per-GPU batch size")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--mfma", default="bf16x3", choices=["f32", "f16x2", "bf16x3", "bf16x2", "bf16"],
-                    help="MFMA mode of the 256 x 256 forward / backward GEMMs: bf16x3 (default: three-term split, six products, holds the "
-                         "fp32 parity tolerances), exact fp32 (the parity-test mode), bf16x2 (~6e-6) or plain bf16 (~3e-3)")
+    ap.add_argument("--mfma", default="f16x2", choices=["f32", "f16x2", "bf16x3", "bf16x2", "bf16"],
+                    help="MFMA mode of the 256 x 256 GEMMs: f16x2 (default: two fp16 terms, three products, holds the fp32 parity "
+                         "tolerances), bf16x3 (three bf16 terms, six products, same grade), exact fp32, bf16x2 (~6e-6) or plain bf16 (~3e-3)")
     ap.add_argument("--no_mode_sweep", action="store_true", help="skip the short runs of the other MFMA modes")
     ap.add_argument("--graph", type=int, default=1, help="HIP-graph replay of the steady-state step: 0 never, 1 always, 2 auto (minibatches under 4096 rows); with N > 1 ranks the segments between the three all-reduces are replayed")
     args = ap.parse_args()
@@ -350,9 +450,14 @@ def main():
         else:
             torch.distributed.init_process_group(backend)
         world = torch.distributed.get_world_size()          # what the process group actually sees
+    if args.config == "pretrain":
+        return bench_pretrain(args, dev, world, rank)
     c = dict(CONFIGS[args.config])
     if args.batch_size:
         c["bs"] = args.batch_size
+    if args.penalty:
+        c["penalty_type"] = args.penalty
+        c["label"] += f", penalty_type {args.penalty}"
     S, A, bs = c["S"], c["A"], c["bs"]
     N, Nt = int(2.5 * bs), 2 * bs
     pol, src, tar, cfg = build(dev, c, args.graph, args.mfma)
@@ -364,24 +469,24 @@ def main():
 
     for _ in range(max(args.warmup, 1)):                  # step 1 includes the full model-rollout refresh (and the DARA warm-up)
         pol.train(src, tar, bs, None, None)
-    scaled_refresh(pol, src, tar, bs, args.steps)         # warm the scaled refresh's shapes too
     barrier()
     import gc
     gc.collect(); gc.disable()                            # a generation-2 collection inside the timed loop is a 40 ms host stall
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     t0 = time.perf_counter()
-    ev[0].record()
-    for _ in range(args.steps):
+    for _ in range(args.steps):                           # EXACTLY K steps between two barrier + synchronize pairs
         pol.train(src, tar, bs, None, None)
-    ev[1].record()
-    rolled = scaled_refresh(pol, src, tar, bs, args.steps)
     barrier()
     t1 = time.perf_counter()
+    # one refresh at the reference's full size, timed on its own and charged at its cadence (once per 5000 steps)
+    rolled = full_refresh(pol, src, tar, bs)
+    barrier()
+    t2 = time.perf_counter()
     gc.enable()
-    t = torch.tensor([t1 - t0, ev[0].elapsed_time(ev[1]) * 1e-3], dtype=torch.float64, device=dev)
+    t = torch.tensor([t1 - t0, t2 - t1], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt, dt_steps = float(t[0]), float(t[1])
+    dt_steps, dt_refresh = float(t[0]), float(t[1])
+    ms_step = dt_steps / args.steps * 1e3 + dt_refresh * 1e3 / REFRESH_EVERY
     losses = pol.losses()
     replicas_identical = None
     if world > 1:                                         # data-parallel replicas must still be bit-identical
@@ -431,51 +536,62 @@ def main():
                         unit="TFLOP/s", traffic=None, avg_launch_ms=avg_ms, launches_per_step=d["launches_per_step"],
                         flops_per_launch=per_launch_flops,
                         peak_note="fp32-equivalent TFLOP/s of the kernel's algorithmic flops if its fp32-MFMA part ran at 157.3 TF and "
-                                  f"its 256x256 GEMMs ({NPROD[args.mfma]} bf16 MFMAs per fp32 product) at 2.5 PF" if args.mfma != "f32"
+                                  f"its 256x256 GEMMs ({NPROD[args.mfma]} 16-bit MFMAs per fp32 product) at 2.5 PF" if args.mfma != "f32"
                                   else "dense fp32-input MFMA peak")
         roofline["frac"] = roofline["achieved"] / roofline["peak"]
         # HBM bytes of one launch of the dominant kernel: PMC counters need their own rocprofv3 passes (FETCH_SIZE and
-        # WRITE_SIZE cannot share one, and not with a timing run), so the figure comes from the committed summary of
-        # those passes over this same command (profiles/, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note)
-        for tag in ("r02", "r01_f"):
+        # WRITE_SIZE cannot share one, and not with a timing run), so the figure can only come from a summary of those
+        # passes over this same command.  It is used ONLY when that summary was measured on exactly this build (source
+        # fingerprint recorded by tools/pmc_traffic.py); anything else is reported as null with the reason.
+        fp = src_fingerprint()
+        roofline["traffic_note"] = f"null: no PMC summary for this build (source fingerprint {fp}) under profiles/"
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")))
-            except OSError:
+                pm = json.load(open(path))
+            except (OSError, ValueError):
                 continue
-            sel = [e for e in pm if dom in e["kernel"] and e["fetch_kb_raw"] and e["write_kb"]]
-            if sel and args.config == "c2" and bs == CONFIGS["c2"]["bs"]:
+            if not isinstance(pm, dict) or pm.get("src_fingerprint") != fp or pm.get("config") != args.config or pm.get("mfma") != args.mfma:
+                continue
+            sel = [e for e in pm["kernels"] if dom in e["kernel"] and e["fetch_kb_raw"] and e["write_kb"]]
+            if sel and bs == CONFIGS[args.config]["bs"]:
                 top = max(e["launches"] for e in sel)
                 sel = [e for e in sel if 2 * e["launches"] >= top]          # the train() step's launches of this family
                 n = sum(e["launches"] for e in sel)
                 roofline["traffic"] = sum((2.0 * e["fetch_kb_raw"] + e["write_kb"]) * 1024.0 * e["launches"] for e in sel) / n
-                roofline["traffic_note"] = f"profiles/{tag}_pmc_traffic.json, launch-weighted mean over " + "; ".join(
-                    f"{e['launches']} x {e['kernel'].strip()} grid {e['grid']}" for e in sel)
-            break
+                roofline["traffic_note"] = (f"{os.path.relpath(path, ROOT)} (same source fingerprint; FETCH_SIZE doubled per "
+                                            "MI355X_MICROARCH.md), launch-weighted mean over " + "; ".join(
+                                                f"{e['launches']} x {e['kernel'].strip()} grid {e['grid']}" for e in sel))
+                break
         graph_on = bool(args.graph == 1 or (args.graph == 2 and N < 4096))
         out = {
             "metric": "transitions/sec (minibatch rows through train(), refresh amortised at 1/5000) + grad-steps/sec",
-            "value": N * world * args.steps / dt, "unit": "transitions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "value": N * world / (ms_step * 1e-3), "unit": "transitions/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.mfma, "data": "synthetic",
             "dtype_note": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference's arithmetic",
                            "bf16x3": "fp32 operands as three bf16 terms, six bf16 MFMAs per fp32 product, fp32 accumulate: fp32-grade "
                                      "(~5e-7 of max|out| from the fp32 kernels); holds the fp32 parity tolerances against the reference's "
-                                     "golden vectors (tests/test_hip_precision.py; the whole -m gpu suite passes with MOBODY_MFMA=bf16x3); "
-                                     "the exact-fp32 step time of the same run is under other_mfma_modes.f32",
+                                     "golden vectors (tests/test_hip_precision.py)",
                            "f16x2": "fp32 operands as two fp16 terms (22 significand bits) with exact power-of-two tile scales, three "
-                                    "fp16 MFMAs per fp32 product, fp32 accumulate: fp32-grade; holds the fp32 parity tolerances "
-                                    "against the reference's golden vectors",
+                                    "fp16 MFMAs per fp32 product, fp32 accumulate: fp32-grade (~3e-7 of max|out| from the fp32 kernels); "
+                                    "every golden-vector suite of `pytest -m gpu` runs in this mode AND in exact fp32 (tests/conftest.py "
+                                    "`mfma` fixture) at the same tolerances; the exact-fp32 step time of the same run is under "
+                                    "other_mfma_modes.f32",
                            "bf16x2": "two bf16 terms, three products (~6e-6): throughput mode, not parity grade",
                            "bf16": "plain bf16 MFMA inputs (~3e-3): throughput mode, not parity grade"}[args.mfma],
             "config": {"workload": f"{args.config}: {c['label']} (S={S} A={A}, ensemble 7, rollout_len {c['H']}, N={N} rows per "
                                    f"train() step: src|tar|fake = {bs}|{bs}|{bs // 2}), "
                                    + ("exact fp32 MFMA" if args.mfma == "f32" else f"256x256 GEMMs (forward, backward, weight gradient) on the {args.mfma} split-precision MFMA "
-                                      "core, everything else exact fp32 MFMA"),
+                                      "core, everything else exact fp32 MFMA") + f", penalty_type {c['penalty_type']}",
                        "name": args.config, "rows_per_step_per_gpu": N, "parallelism": f"dp{world}", "hip_graph": graph_on},
-            "grad_steps_per_sec": args.steps / dt,
+            "grad_steps_per_sec": 1e3 / ms_step,
             "grad_steps_per_sec_refresh_excluded": args.steps / dt_steps,
+            "timed_region": {"steps_ms": dt_steps * 1e3, "steps": args.steps,
+                             "note": "ms_per_step = steps_ms / steps + refresh.ms / 5000 (one full-size refresh timed after the K steps)"},
+            "refresh": {"rows": rolled, "ms": dt_refresh * 1e3, "ms_per_step_share": dt_refresh * 1e3 / REFRESH_EVERY,
+                        "transitions_per_sec": rolled / dt_refresh},
             "rollout_transitions_per_sec": roll_rate, "rollout_ms_per_call": roll_ms,
-            "rollout_rows_in_timed_region": rolled,
             "roofline": roofline, "kernels": kern, "final_losses": losses, "replicas_identical": replicas_identical,
             "other_mfma_modes": sweep,
         }

@@ -131,7 +131,9 @@ int mobody_dyn_planes(const float* dyn_blob, int S, int A, float* planes, int pr
 int64_t mobody_dyn_step_workspace(int S, int A, int64_t B);
 
 /* One imagined transition for B rows (A.1 of SURVEY.md).
- *   noise      [E][B][S] unit normals, or NULL -> generated on device from (seed, call)
+ *   noise      [E][B][S] unit normals, or NULL -> generated on device from (seed, call + call_dev[0])
+ *   call_dev   optional device int64 word added to `call` (NULL = 0): a captured HIP graph keeps its step counter on the
+ *              device, so every replay draws fresh noise without new kernel arguments
  *   elite_idx  [B] member id per row,   or NULL -> elites[philox % n_elites]
  *   alive      [B] optional uint8 mask (NULL = all alive); dead rows are computed but flagged
  *              terminal=1 so an on-device multi-step rollout can keep fixed row indices
@@ -142,7 +144,8 @@ int mobody_dyn_step(const float* dyn_blob, const float* dyn_planes, int precisio
                     const float* obs, const float* act, int64_t B,
                     const float* noise, const int32_t* elite_idx, const uint8_t* alive, const int32_t* elites,
                     int n_elites, uint32_t seed,
-                    uint32_t call, float penalty_coef, int use_penalty, int use_trg, float* next_obs, float* reward,
+                    uint32_t call, const int64_t* call_dev, float penalty_coef, int use_penalty, int use_trg, float* next_obs,
+                    float* reward,
                     uint8_t* terminal, float* penalty, float* raw_reward, float* mean_out, float* workspace,
                     void* stream);
 

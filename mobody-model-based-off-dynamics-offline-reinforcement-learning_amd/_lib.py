@@ -74,7 +74,7 @@ PROTOTYPES = {
     "mobody_dyn_planes": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "mobody_dyn_step_workspace": (i64, [C.c_int, C.c_int, i64]),
     "mobody_dyn_step": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, i64, vp, vp, vp, C.POINTER(i32), C.c_int,
-                                  u32, u32, f32, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
+                                  u32, u32, vp, f32, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mobody_mopo_step": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, i64, vp, vp, vp, C.POINTER(i32), C.c_int,
                                    u32, u32, f32, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mobody_rollout_workspace": (i64, [C.c_int, C.c_int, i64]),

@@ -76,13 +76,18 @@ class MOBODYEnsembleDynamics(object):
                             "(the predicate is evaluated inside the fused kernel)")
         self._task_id = task_id
 
-    def step_device(self, obs, action, use_penalty=True, use_trg=True, alive=None, want_mean=False, elite_idx=None):
+    def step_device(self, obs, action, use_penalty=True, use_trg=True, alive=None, want_mean=False, elite_idx=None,
+                    call=None, call_dev=None, seed_offset=0):
+        """call / call_dev / seed_offset: explicit noise-stream position (call + call_dev[0], device word) for a captured
+        HIP graph, whose replays cannot advance the host-side call counter."""
         m = self.model
         m.inference()
         obs = torch.as_tensor(obs, dtype=torch.float32).to(m.device).contiguous()
         action = torch.as_tensor(action, dtype=torch.float32).to(m.device).reshape(-1, m.action_dim).contiguous()
         B = obs.shape[0]
-        self._calls += 1
+        if call is None:
+            self._calls += 1
+            call = self._calls
         noise = self.noise_fn((7, B, m.obs_dim)) if self.noise_fn is not None else None
         if elite_idx is None and self.rng == "numpy":
             elite_idx = m.random_elite_idxs(B)
@@ -90,8 +95,8 @@ class MOBODYEnsembleDynamics(object):
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 1), dtype=torch.float32, device=m.device)
         return ops.dyn_step(m.packed(), m.obs_dim, m.action_dim, self._task_id, obs, action, noise=noise,
-                            elite_idx=elite_idx, alive=alive, elites=[int(e) for e in m.elites.tolist()],
-                            seed=(self.seed + dp.rank_salt()) & 0xFFFFFFFF, call=self._calls,
+                            elite_idx=elite_idx, alive=alive, elites=m.elites_host(),
+                            seed=(self.seed + seed_offset + dp.rank_salt()) & 0xFFFFFFFF, call=call, call_dev=call_dev,
                             penalty_coef=float(self._penalty_coef or 0.0),
                             use_penalty=bool(use_penalty), use_trg=bool(use_trg), want_mean=want_mean,
                             workspace=self._ws, planes=m.planes() if self.precision else None, precision=self.precision,

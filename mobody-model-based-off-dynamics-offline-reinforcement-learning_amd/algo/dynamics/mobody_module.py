@@ -73,6 +73,15 @@ class MOBODYModule(object):
     def elites(self):
         return self._p["elites"]
 
+    def elites_host(self):
+        """The elite member ids as a host tuple, cached per elites tensor (a captured HIP graph may not read device memory
+        from the host; the kernels take the ids as launch arguments)."""
+        t = self._p["elites"]
+        c = getattr(self, "_elites_host", None)
+        if c is None or c[0] is not t:
+            self._elites_host = c = (t, tuple(int(e) for e in t.tolist()))
+        return c[1]
+
     def state_dict(self):
         self._sync_from_train()
         return {k: v.detach().clone() for k, v in self._p.items()}

@@ -24,6 +24,7 @@ from .. import utils
 REFRESH_EVERY = 5000        # mobody.py:441
 REFRESH_SRC, REFRESH_TAR = 50000, 2000    # :442-443
 REFRESH_FROM_SRC_TAR = 100                # target init states of the rollout_from_src branch, :485
+GRAPH_DYN_SEED = 0x51ED                    # seed offset of the ensemble-step noise stream of captured 'par' steps
 
 
 class _PackedNet(object):
@@ -224,7 +225,7 @@ class MOBODY(object):
         # one GPU: the gradient reduction applies Adam/Polyak itself (mobody_critic_update / mobody_actor_update);
         # config['fused_update']=0 keeps the separate gradient blobs + optimizer launches (what N > 1 ranks use)
         self.fused_update = int(config.get("fused_update", 1))
-        self._ctr = torch.zeros(3, dtype=torch.int64, device=self.device)      # [rng call, critic t, actor t]
+        self._ctr = torch.zeros(4, dtype=torch.int64, device=self.device)      # [rng call, critic t, actor t, V t]
         self._synced = False                   # data parallel: replicas broadcast from rank 0 before the first step
         self.classifier_noise_fn = None        # optional hook: n_rows -> (noise_sas[n,2S+A], noise_sa[n,S+A]) (tests)
 
@@ -371,7 +372,7 @@ class MOBODY(object):
         B = obs.shape[0]
         m.inference()
         self._roll_ws = ops.rollout(m.packed(), self.policy.blob, self.S, self.A, dyn._task_id, self.policy.max_action, obs,
-                                    rollout_length, [int(e) for e in m.elites.tolist()],
+                                    rollout_length, list(m.elites_host()),
                                     (dyn.seed + dp.rank_salt()) & 0xFFFFFFFF, dyn._calls + 1, float(dyn._penalty_coef or 0.0),
                                     use_trg, True, self.config["env_filter"], self.config["filter_bad_rollout"],   # quirk Q1
                                     fb._fields(), fb.max_size, fb.ptr_size, getattr(self, "_roll_ws", None),
@@ -417,9 +418,15 @@ class MOBODY(object):
     # ------------------------------------------------------------------ HIP-graph fast path
     def _graph_ok(self, writer):
         want = self.use_graph == 1 or (self.use_graph == 2 and self._batch[0].shape[0] < 4096)
-        # 'dara' only acts in the very first call (classifier warm-up + one-off reward rewrite); 'par' relabels every step
-        return (want and self.rng == "device" and self.penalty_type != "par"
-                and not self.config["advantage"] and (self.total_it - 1) % REFRESH_EVERY != 0
+        # 'dara' only acts in the very first call (classifier warm-up + one-off reward rewrite).  'par' (the CLI's default,
+        # mobody.py:428-434) relabels the source rows every step: its ensemble step and the reward shaping are captured with
+        # the step, the noise call id read from the device counter.  The V phase of `advantage` is captured on one GPU (its
+        # gradient all-reduce belongs to the eager exchange protocol).
+        dyn = self.dynamics
+        par_ok = self.penalty_type != "par" or (dyn is not None and getattr(dyn, "noise_fn", None) is None
+                                                and dyn.rng == "device" and not getattr(dyn.model, "mopo", False))
+        adv_ok = not self.config["advantage"] or (self._world() == 1 and self.fused_update and self._v_ws is not None)
+        return (want and self.rng == "device" and par_ok and adv_ok and (self.total_it - 1) % REFRESH_EVERY != 0
                 and not (writer is not None and self.total_it % 5000 == 0))
 
     @staticmethod
@@ -441,10 +448,20 @@ class MOBODY(object):
         if nf > 0:
             bufs.append(self.fake_replay_buffer); cnts.append(nf); seeds.append(self._seed_for(103))
 
+        par = self.penalty_type == "par"
+
+        def par_relabel(call):
+            # mobody.py:428-434: one ensemble step on the source rows, r -= coef * mean_d (s'_true - s'_model)^2; the noise
+            # stream position is `call` + the device counter (a stream of its own: seed offset GRAPH_DYN_SEED)
+            r = self.dynamics.step_device(b[0][:ns], b[1][:ns], call=call, call_dev=c[0:1], seed_offset=GRAPH_DYN_SEED)
+            ops.par_penalty(b[2][:ns], r["next_obs"], b[3][:ns], cfg["penalty_coef"])
+
         def critic():
-            ops.counter_add(c)
+            ops.counter_add(c[0:3])
             ops.gather_batch_rng([rb._fields() for rb in bufs], cnts, seeds, [0] * len(bufs), c[0:1],
                                  [rb.ptr_size[1:2] for rb in bufs], S, A, b)
+            if par:
+                par_relabel(0)
             self.critic_grad(b, N, Nt, Ng, Ntg)
 
         def critic_apply_actor_stats():
@@ -455,7 +472,12 @@ class MOBODY(object):
             # no launch of its own for the three counters: the gather draws with call id c[0] + 1 and advances the two Adam
             # step counts (it does not read them), the critic's optimizer launch advances c[0] (the gather is done with it)
             ops.gather_batch_rng([rb._fields() for rb in bufs], cnts, seeds, [1] * len(bufs), c[0:1],
-                                 [rb.ptr_size[1:2] for rb in bufs], S, A, b, bump=(c[1:2], c[2:3]))
+                                 [rb.ptr_size[1:2] for rb in bufs], S, A, b, bump=(c[1:2], c[2:3], c[3:4]))
+            if par:
+                par_relabel(1)
+            if cfg["advantage"]:                                             # V update first (mobody.py:533-537)
+                self.value_grad(b, N, Nt, N, Nt)
+                self.v_optimizer.step_dev(c[3:4])
             self.critic_update(b, N, Nt, t_dev=c[1:2], bump=c[0:1])
             self.actor_stats(b, N, Nt, N, Nt)
             self.actor_update(b, N, Nt, t_dev=c[2:3])
@@ -492,17 +514,27 @@ class MOBODY(object):
         # every device pointer the captured kernels read or write: a reloaded checkpoint, a re-assigned fake buffer
         # or a resized minibatch must force a re-capture (replaying against freed tensors corrupts memory silently)
         fb = self.fake_replay_buffer
-        nets = (self.q_funcs, self.target_q_funcs, self.policy)
-        opts = (self.q_optimizer, self.policy_optimizer)
+        nets = (self.q_funcs, self.target_q_funcs, self.policy, self.v_func)
+        opts = (self.q_optimizer, self.policy_optimizer, self.v_optimizer)
+        dyn_key = None
+        if self.penalty_type == "par":                  # the captured ensemble step reads these
+            m = self.dynamics.model
+            dyn_key = (m.packed().data_ptr(), m.planes().data_ptr() if self.dynamics.precision else 0, self.dynamics.precision,
+                       m.elites_host(), float(self.dynamics._penalty_coef or 0.0))
         key = (batch_size, id(src), id(tar), src.state.data_ptr(), tar.state.data_ptr(), world, segmented,
                id(fb), fb.state.data_ptr(), fb.ptr_size.data_ptr(), tuple(t.data_ptr() for t in self._batch),
                tuple((n.blob.data_ptr(), n.blob_T.data_ptr()) for n in nets), self.precision,
                tuple((o.m.data_ptr(), o.v.data_ptr(), o.grad.data_ptr()) for o in opts),
-               None if self._ws is None else self._ws.data_ptr(), self.dp_graph)
+               None if self._ws is None else self._ws.data_ptr(), self.dp_graph, dyn_key,
+               None if self._v_ws is None else self._v_ws.data_ptr())
         if self._graph is None or self._graph_key != key:
             torch.cuda.synchronize()
             self._ctr[1] = self.q_optimizer.t
             self._ctr[2] = self.policy_optimizer.t
+            self._ctr[3] = self.v_optimizer.t
+            if self.penalty_type == "par":               # size the ensemble step's workspace outside the capture
+                self.dynamics.step_device(self._batch[0][:int(self.config["src_ratio"] * batch_size)],
+                                          self._batch[1][:int(self.config["src_ratio"] * batch_size)], call=0)
             graphs = []
             try:
                 for seg in self._graph_segments(src, tar, batch_size, world, segmented):
@@ -536,6 +568,8 @@ class MOBODY(object):
             gd.replay()
         self.q_optimizer.t += 1
         self.policy_optimizer.t += 1
+        if self.config["advantage"]:
+            self.v_optimizer.t += 1
         return True
 
     def train(self, src_replay_buffer, tar_replay_buffer, batch_size=128, writer=None, wandbrun=None):

@@ -163,6 +163,7 @@ struct DynSampleArgs {
   int32_t elites[NENS];
   int n_elites;
   uint32_t seed, call;
+  const long long* call_dev; // optional device word added to `call` (graph replay: the step counter lives on the device)
   long long B;
   int S, task;
   float* next_obs;           // [B][S]
@@ -210,10 +211,11 @@ __global__ __launch_bounds__(256) void k_dyn_sample(DynSampleArgs a, int rpb) {
   const int r = tid / S, d = tid - r * S;
   const long long row0 = (long long)blockIdx.x * rpb;
   const long long b = row0 + r;
+  const uint32_t call = a.call + (a.call_dev != nullptr ? (uint32_t)a.call_dev[0] : 0u);
   if (r < rpb && b < a.B) {
     int e_sel;
     if (a.elite_idx) e_sel = a.elite_idx[b];
-    else e_sel = a.elites[rng_index_at(a.seed, STREAM_ELITE, a.call, (uint64_t)b, (uint32_t)a.n_elites)];
+    else e_sel = a.elites[rng_index_at(a.seed, STREAM_ELITE, call, (uint64_t)b, (uint32_t)a.n_elites)];
     float mval[NENS], avg = 0.f, msel = 0.f;
 #pragma unroll
     for (int e = 0; e < NENS; ++e) {
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256) void k_dyn_sample(DynSampleArgs a, int rpb) {
     const float sd = sqrtf(var * (1.f / (NENS - 1)));                      // torch.std: unbiased (:218)
     float eps;
     if (a.noise) eps = a.noise[((long long)e_sel * a.B + b) * S + d];
-    else eps = rng_normal_at(a.seed, STREAM_NOISE, a.call, (uint64_t)b * S + d);
+    else eps = rng_normal_at(a.seed, STREAM_NOISE, call, (uint64_t)b * S + d);
     const float v = msel + eps * sd;                                       // :220-226
     a.next_obs[b * S + d] = v;
     s_nxt[tid] = v;
@@ -391,7 +393,7 @@ extern "C" int64_t mobody_dyn_step_workspace(int S, int A, int64_t B) {
 static int dyn_step_impl(const float* dyn_blob, const float* dyn_planes, const float* mopo_blob, const float* mopo_blob_T,
                          int precision, int S, int A, int task, const float* obs, const float* act,
                          int64_t B, const float* noise, const int32_t* elite_idx, const uint8_t* alive,
-                         const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty,
+                         const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, const int64_t* call_dev, float penalty_coef, int use_penalty,
                          int use_trg, float* next_obs, float* reward, uint8_t* terminal, float* penalty,
                          float* raw_reward, float* mean_out, float* workspace, uint8_t* keep, uint8_t* alive_out,
                          float env_filter, int use_filter, void* stream) {
@@ -440,7 +442,7 @@ static int dyn_step_impl(const float* dyn_blob, const float* dyn_planes, const f
   DynSampleArgs sa{};
   sa.mean = mean; sa.noise = noise; sa.elite_idx = elite_idx; sa.alive = alive;
   for (int k = 0; k < NENS; ++k) sa.elites[k] = (elites && k < n_elites) ? elites[k] : 0;
-  sa.n_elites = n_elites; sa.seed = seed; sa.call = call; sa.B = B; sa.S = S; sa.task = task;
+  sa.n_elites = n_elites; sa.seed = seed; sa.call = call; sa.call_dev = (const long long*)call_dev; sa.B = B; sa.S = S; sa.task = task;
   sa.next_obs = next_obs; sa.penalty = penalty; sa.terminal = terminal;
   sa.keep = keep; sa.alive_out = alive_out; sa.env_filter = env_filter; sa.use_filter = use_filter;
   const int rpb = 256 / S < 64 ? 256 / S : 64;         // whole rows per workgroup (S <= 256 is checked by the layout)
@@ -477,11 +479,12 @@ static int dyn_step_impl(const float* dyn_blob, const float* dyn_planes, const f
 extern "C" int mobody_dyn_step(const float* dyn_blob, const float* dyn_planes, int precision, int S, int A, int task,
                                const float* obs, const float* act,
                                int64_t B, const float* noise, const int32_t* elite_idx, const uint8_t* alive,
-                               const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, float penalty_coef, int use_penalty,
+                               const int32_t* elites, int n_elites, uint32_t seed, uint32_t call, const int64_t* call_dev,
+                               float penalty_coef, int use_penalty,
                                int use_trg, float* next_obs, float* reward, uint8_t* terminal, float* penalty,
                                float* raw_reward, float* mean_out, float* workspace, void* stream) {
   return dyn_step_impl(dyn_blob, dyn_planes, nullptr, nullptr, precision, S, A, task, obs, act, B, noise, elite_idx, alive, elites, n_elites, seed,
-                       call, penalty_coef, use_penalty, use_trg, next_obs, reward, terminal, penalty, raw_reward, mean_out, workspace,
+                       call, call_dev, penalty_coef, use_penalty, use_trg, next_obs, reward, terminal, penalty, raw_reward, mean_out, workspace,
                        nullptr, nullptr, 0.f, 0, stream);
 }
 
@@ -493,7 +496,7 @@ extern "C" int mobody_mopo_step(const float* dyn_blob, const float* dyn_planes, 
                                 float* workspace, void* stream) {
   MB_REQUIRE(B == 0 || mopo_blob != nullptr, "mobody_mopo_step: null MLP blob");
   return dyn_step_impl(dyn_blob, dyn_planes, mopo_blob, mopo_blob_T, precision, S, A, task, obs, act, B, noise, elite_idx, alive, elites,
-                       n_elites, seed, call, penalty_coef, use_penalty, 1, next_obs, reward, terminal, penalty, raw_reward, mean_out,
+                       n_elites, seed, call, nullptr, penalty_coef, use_penalty, 1, next_obs, reward, terminal, penalty, raw_reward, mean_out,
                        workspace, nullptr, nullptr, 0.f, 0, stream);
 }
 
@@ -564,7 +567,7 @@ extern "C" int mobody_rollout(const float* dyn_blob, const float* dyn_planes, co
     // one imagined transition for every row; rows that terminated earlier keep their index and are flagged (alive mask);
     // the penalty filter and the alive update are formed in the sample kernel
     rc = dyn_step_impl(dyn_blob, dyn_planes, nullptr, nullptr, precision, S, A, task, obs, w.act, B, nullptr, nullptr, t == 0 ? nullptr : w.alive, elites, n_elites, seed,
-                       call0 + (uint32_t)t, penalty_coef, use_penalty, use_trg, nxt, w.reward, w.terminal, w.penalty, nullptr, nullptr,
+                       call0 + (uint32_t)t, nullptr, penalty_coef, use_penalty, use_trg, nxt, w.reward, w.terminal, w.penalty, nullptr, nullptr,
                        w.dyn, w.keep, w.alive, env_filter, filter_bad_rollout, stream);
     if (rc) return rc;
     rc = launch_ring_append(*ring, cap, (long long*)ptr_size, S, A, obs, w.act, nxt,

@@ -61,9 +61,10 @@ def dyn_forward(blob, S, A, obs, act, use_trg=True, planes=None, precision=0):
 
 def dyn_step(blob, S, A, task_id, obs, act, noise=None, elite_idx=None, alive=None, elites=(0, 1, 2, 3, 4), seed=0,
              call=0, penalty_coef=0.0, use_penalty=True, use_trg=True, want_mean=False, workspace=None, out=None,
-             planes=None, precision=0, mopo=None):
+             planes=None, precision=0, mopo=None, call_dev=None):
     """Returns dict(next_obs[B,S], reward[B,1], terminal uint8[B,1], penalty[B,1], raw_reward[B,1], mean?).
-    mopo = (blob, blob_T) of the 7-member MLP za_src1..3: the MOPO ablation's step (mobody_mopo_step)."""
+    mopo = (blob, blob_T) of the 7-member MLP za_src1..3: the MOPO ablation's step (mobody_mopo_step).
+    call_dev: device int64[1] added to `call` (graph replay)."""
     obs, act = _f32(obs), _f32(act)
     dev, B = obs.device, obs.shape[0]
     if noise is not None:
@@ -94,7 +95,7 @@ def dyn_step(blob, S, A, task_id, obs, act, noise=None, elite_idx=None, alive=No
             res["mean"] = mean
         return res
     check(load().mobody_dyn_step(ptr(blob), ptr(planes), prec_id(precision), S, A, task_id, ptr(obs), ptr(act), B, ptr(noise), ptr(elite_idx),
-                                 ptr(alive), el, len(elites), seed, call, float(penalty_coef), int(bool(use_penalty)),
+                                 ptr(alive), el, len(elites), seed, call, ptr(call_dev), float(penalty_coef), int(bool(use_penalty)),
                                  int(bool(use_trg)), ptr(nxt), ptr(rew), ptr(term), ptr(pen), ptr(raw), ptr(mean),
                                  ptr(workspace), cur_stream()), "mobody_dyn_step")
     res = dict(next_obs=nxt, reward=rew, terminal=term, penalty=pen, raw_reward=raw)

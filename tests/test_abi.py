@@ -78,9 +78,9 @@ def test_argument_validation_reports_errors(lib):
     d = _lib.MobodyTrainDims(17, 6, 640, 512, 640, 512)
     assert lib.mobody_train_workspace(C.byref(d)) > 640 * 256 * 8
     # empty batches are accepted without touching any pointer
-    assert lib.mobody_dyn_step(None, None, 0, 17, 6, 4, None, None, 0, None, None, None, None, 0, 0, 0, 0.0, 1, 1, None, None,
+    assert lib.mobody_dyn_step(None, None, 0, 17, 6, 4, None, None, 0, None, None, None, None, 0, 0, 0, None, 0.0, 1, 1, None, None,
                                None, None, None, None, None, None) == 0
-    assert lib.mobody_dyn_step(None, None, 0, 17, 6, 99, None, None, 5, None, None, None, None, 0, 0, 0, 0.0, 1, 1, None, None,
+    assert lib.mobody_dyn_step(None, None, 0, 17, 6, 99, None, None, 5, None, None, None, None, 0, 0, 0, None, 0.0, 1, 1, None, None,
                                None, None, None, None, None, None) == -1
 
 

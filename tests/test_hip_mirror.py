@@ -252,20 +252,28 @@ def test_first_train_call_refreshes_fake_buffer_and_checkpoints_round_trip(dev, 
     pol.dynamics.load(str(d))
 
 
-def test_graph_replay_matches_eager_steps(mfma, dev):
+@pytest.mark.parametrize("variant", ["none", "par", "advantage"])
+def test_graph_replay_matches_eager_steps(variant, mfma, dev):
     """config['graph']=1: the captured steady-state step (device-side RNG call / Adam step counters) produces the
-    same parameters as eager execution fed with the same device draws."""
+    same parameters as eager execution fed with the same device draws -- also for the CLI's default penalty_type='par'
+    (one ensemble step + reward shaping on the source rows every step, mobody.py:428-434) and for the `advantage`
+    variant's V phase (mobody.py:210-242,533-542), both captured inside the graph."""
     from mobody_amd import synthetic, ops
     from mobody_amd.algo import utils
     from mobody_amd.algo.call_algo import call_algo
+    from mobody_amd.algo.offline_offline.mobody import GRAPH_DYN_SEED
     S, A, task, bs = 17, 6, "walker2d-medium-v2", 64
     fake_rows = gu.gi.batch(9, 300, S, A)
+    over = dict(par=dict(penalty_type="par"), advantage=dict(advantage=1), none={})[variant]
+    p_dyn = gu.gi.dyn_params(31, S, A)
+    p_dyn["transition3.bias"][:, 0, 0] += np.float32(1.0)
 
     def make(graph):
         torch.manual_seed(3)
         cfg = gu.policy_cfg(S, A, rng="device", seed=7, graph=graph, src_rollout_length=0, trg_rollout_length=0,
-                            use_src_sa_to_get_target_next_state=0)
+                            use_src_sa_to_get_target_next_state=0, **over)
         pol = call_algo("mobody", cfg, 3, dev)
+        pol.dynamics = make_dynamics(p_dyn, S, A, task, dev, cfg, rng="device", seed=13)
         pol.fake_replay_buffer.add_batch(dict(obss=fake_rows[0], actions=fake_rows[1], next_obss=fake_rows[2],
                                               rewards=fake_rows[3], terminals=1.0 - fake_rows[4]))
         src = synthetic.fill_buffer(utils.ReplayBuffer(S, A, dev, max_size=4000, rng="device", seed=1), 4000, task, 0)
@@ -276,23 +284,33 @@ def test_graph_replay_matches_eager_steps(mfma, dev):
     g.train(gs, gt, bs, None, None)              # step 1: eager (refresh step; rollouts disabled by the config)
     for _ in range(3):
         g.train(gs, gt, bs, None, None)          # steps 2-4: captured graph
-    assert g._graph is not None and g.q_optimizer.t == 4 and g._ctr.tolist() == [3, 4, 4]
+    assert g._graph is not None and g.q_optimizer.t == 4 and g._ctr.tolist()[:3] == [3, 4, 4]
+    assert g.v_optimizer.t == (4 if variant == "advantage" else 0)
 
     e, es, et = make(0)
     e.train(es, et, bs, None, None)
-    # replay the graph's index draws eagerly: call ids 1..3 on the three sampling streams
+    # replay the graph's index draws eagerly: call ids 1..3 on the three sampling streams (and on the ensemble step's
+    # noise stream for 'par')
     for call in (1, 2, 3):
         e.total_it += 1
         c = torch.tensor([call], dtype=torch.int64, device=dev)
         idx = [ops.sample_indices(7 + 101, 3, c, 0, bs, es.ptr_size[1:2]), ops.sample_indices(7 + 102, 3, c, 0, bs, et.ptr_size[1:2]),
                ops.sample_indices(7 + 103, 3, c, 0, bs // 2, e.fake_replay_buffer.ptr_size[1:2])]
         ops.gather_batch([es._fields(), et._fields(), e.fake_replay_buffer._fields()], idx, S, A, out=e._batch)
+        if variant == "par":
+            b = e._batch
+            r = e.dynamics.step_device(b[0][:bs], b[1][:bs], call=call, seed_offset=GRAPH_DYN_SEED)
+            ops.par_penalty(b[2][:bs], r["next_obs"], b[3][:bs], e.config["penalty_coef"])
         e._update(e._batch, int(2.5 * bs), 2 * bs)
     torch.cuda.synchronize()
     # the device-side Adam bias corrections use the GPU's double pow; the host path uses libm: allow 1 ulp of fp32
     close(g.q_funcs.blob, e.q_funcs.blob, rtol=1e-6, atol=1e-8)
     close(g.policy.blob, e.policy.blob, rtol=1e-6, atol=1e-8)
     close(g.target_q_funcs.blob, e.target_q_funcs.blob, rtol=1e-6, atol=1e-8)
+    if variant == "advantage":
+        close(g.v_func.blob, e.v_func.blob, rtol=1e-6, atol=1e-8)
+    if variant == "par":                          # the shaped source rewards of the last step agree too
+        close(g._batch[3], e._batch[3], rtol=1e-6, atol=1e-7)
 
 
 def test_dara_classifier_vs_reference_golden(mfma, dev):
@@ -399,7 +417,7 @@ def test_graph_mode_across_refresh_boundaries(dev, monkeypatch):
     torch.cuda.synchronize()
     assert captured == 4 and len(sizes) == 4 and all(b > a for a, b in zip(sizes, sizes[1:])), (captured, sizes)
     assert pol.total_it == 130 and pol.q_optimizer.t == 130 and pol.policy_optimizer.t == 130
-    assert pol._ctr.tolist()[1:] == [130, 130]
+    assert pol._ctr.tolist()[1:3] == [130, 130]
     assert all(np.isfinite(v) for v in pol.losses())
     assert torch.isfinite(pol.policy.blob).all() and torch.isfinite(pol.q_funcs.blob).all()
 
