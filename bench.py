@@ -179,7 +179,9 @@ def full_refresh(pol, src, tar, bs):
     the 50 000 (s, a) relabels; mobody.py:441-475) through the product's own `_refresh`.  Returns the rows it rolled."""
     from mobody_amd.algo.offline_offline import mobody as M
     pol._refresh(src, tar, bs)
-    return M.REFRESH_SRC * pol.config["src_rollout_length"] + M.REFRESH_TAR * pol.config["trg_rollout_length"] + M.REFRESH_SRC
+    w = pol._world()                                     # data parallel: the init states are sharded over the ranks (SURVEY 8e)
+    n_s, n_t = -(-M.REFRESH_SRC // w), -(-M.REFRESH_TAR // w)
+    return n_s * pol.config["src_rollout_length"] + n_t * pol.config["trg_rollout_length"] + n_s
 
 
 def prof_pass(pol, src, tar, bs, steps):
@@ -589,8 +591,8 @@ def main():
             "grad_steps_per_sec_refresh_excluded": args.steps / dt_steps,
             "timed_region": {"steps_ms": dt_steps * 1e3, "steps": args.steps,
                              "note": "ms_per_step = steps_ms / steps + refresh.ms / 5000 (one full-size refresh timed after the K steps)"},
-            "refresh": {"rows": rolled, "ms": dt_refresh * 1e3, "ms_per_step_share": dt_refresh * 1e3 / REFRESH_EVERY,
-                        "transitions_per_sec": rolled / dt_refresh},
+            "refresh": {"rows_per_rank": rolled, "ms": dt_refresh * 1e3, "ms_per_step_share": dt_refresh * 1e3 / REFRESH_EVERY,
+                        "transitions_per_sec": rolled * world / dt_refresh},
             "rollout_transitions_per_sec": roll_rate, "rollout_ms_per_call": roll_ms,
             "roofline": roofline, "kernels": kern, "final_losses": losses, "replicas_identical": replicas_identical,
             "other_mfma_modes": sweep,

@@ -383,10 +383,18 @@ class MOBODY(object):
         return B * rollout_length
 
     def _refresh(self, src_rb, tar_rb, batch_size):
-        """Model-rollout refresh of the fake buffer, mobody.py:441-513."""
+        """Model-rollout refresh of the fake buffer, mobody.py:441-513.
+
+        Data parallel: rollouts have no cross-row coupling, so the 50 000 / 2 000 init states are SHARDED over the
+        ranks -- every rank rolls ceil(n / world) rank-salted draws into its own fake-buffer shard and later samples its slice
+        of the fake batch from that shard; no collective.  The union of the shards is the reference's buffer in distribution,
+        and the refresh costs each rank 1 / world of the single-GPU refresh (`config['shard_refresh'] = 0` keeps every rank on
+        the full counts)."""
         cfg = self.config
-        s_idx = src_rb.draw_indices(REFRESH_SRC)
-        t_idx = tar_rb.draw_indices(REFRESH_TAR)
+        world = self._world() if int(cfg.get("shard_refresh", 1)) else 1
+        n_src, n_tar = -(-REFRESH_SRC // world), -(-REFRESH_TAR // world)
+        s_idx = src_rb.draw_indices(n_src)
+        t_idx = tar_rb.draw_indices(n_tar)
         src = ops.gather_batch([src_rb._fields()], [s_idx], self.S, self.A)
         tar = ops.gather_batch([tar_rb._fields()], [t_idx], self.S, self.A)
         if self.rng == "device" and not getattr(getattr(self.dynamics, "model", None), "mopo", False):
@@ -405,8 +413,8 @@ class MOBODY(object):
         if cfg["rollout_from_src"]:                                           # :479-513
             if self.penalty_type != "dara":
                 self.update_classifier(src_rb, tar_rb, batch_size)                 # train()'s batch_size, :481
-            s_idx = src_rb.draw_indices(REFRESH_SRC)
-            t_idx = tar_rb.draw_indices(REFRESH_FROM_SRC_TAR)
+            s_idx = src_rb.draw_indices(n_src)
+            t_idx = tar_rb.draw_indices(-(-REFRESH_FROM_SRC_TAR // world))
             init = ops.gather_batch([src_rb._fields(), tar_rb._fields()], [s_idx, t_idx], self.S, self.A)[0]
             tr, _ = self.rollout(init, cfg["rollout_from_src_length"], use_trg=False)
             if tr is not None and tr["obss"].shape[0] > 0:

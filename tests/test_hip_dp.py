@@ -197,3 +197,22 @@ def test_two_rank_dara_classifier_update_equals_the_single_rank_update(tmp_path)
         # the two sums are formed in different orders; Adam's 1/sqrt(v) stretches that on near-zero-gradient entries: 2e-6 = 0.2 % of a step
         np.testing.assert_allclose(r0[k].numpy(), one[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
     assert any(float((one[k] - one[k].mean()).abs().max()) > 0 for k in one)
+
+
+def test_bench_two_rank_path_keeps_replicas_identical(tmp_path):
+    """bench.py's OWN `--gpus 2` path (its launcher, rank-salted draws, sync_replicas, the segment-graph step with the three
+    all-reduces between the segments, the rank-sharded refresh, the replica check) rehearsed with two ranks sharing the one
+    GPU of the test box over gloo (RCCL refuses two ranks on one device): rank 0's JSON line must report identical replicas."""
+    import json
+    import subprocess
+    env = dict(os.environ, MOBODY_BENCH_BACKEND="gloo", MASTER_PORT=str(29900 + os.getpid() % 90))
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "c1", "--steps", "6", "--warmup", "2",
+                        "--no_cpu_baseline", "--no_mode_sweep"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["replicas_identical"] is True and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["hip_graph"] is True and d["steps"] == 6
+    assert d["refresh"]["rows_per_rank"] == 25000 + 1000 + 25000          # 50 000 / 2 000 init states sharded over the two ranks
+    assert d["value"] > 0 and all(v == v for v in d["final_losses"])
