@@ -1,5 +1,6 @@
 // Host-side helpers shared by the C-ABI translation units.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <string>
@@ -79,5 +80,17 @@ extern __device__ unsigned long long g_trace[TRACE_BLOCKS * TRACE_SLOTS];
 #else
 #define TR(k)
 #endif
+
+// Tuning knobs (tile heights, launch groupings ... the MOBODY_* environment variables the sweeps of DESIGN section 5 were
+// run with) exist in the diagnostic build only; the product library never reads the environment.
+inline int tune_int(const char* name, int dflt) {
+#ifdef MOBODY_TRACE
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
 
 }  // namespace mobody

@@ -307,7 +307,7 @@ static int launch_dyn_fwd(const float* blob, const MobodyDynLayout& L, const flo
   DynFwdArgs a{blob, L, obs, act, mean, B, use_trg, reinterpret_cast<const unsigned short*>(planes)};
   // 64-row tiles for fp32: the nine-layer chain has a wave-local narrow section in which a 32-row tile idles half of
   // the waves (measured 102 vs 88 TFLOP/s at 50 000 rows); MOBODY_DYN_TILE_ROWS=32 selects the short tile.
-  static const int forced = [] { const char* e = getenv("MOBODY_DYN_TILE_ROWS"); return e ? atoi(e) : 0; }();
+  static const int forced = tune_int("MOBODY_DYN_TILE_ROWS", 0);
   const int np = L.layer[MOBODY_DL_TR3].Np;
   const int nt3 = np == 16 ? 1 : np == 32 ? 2 : np == 48 ? 3 : np == 112 ? 7 : 0;      // walker/hopper/cheetah, pen, ant heads; else generic
   if (prec == 0) return forced == 32 ? launch_dyn_fwd_nt<1, 0>(a, nt3, st) : launch_dyn_fwd_nt<2, 0>(a, nt3, st);

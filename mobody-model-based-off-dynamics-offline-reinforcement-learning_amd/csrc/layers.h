@@ -148,7 +148,7 @@ int launch_mlp3_fwd_bf(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b
 // 2.5 k to 41 k rows (forward 84 vs 73 TFLOP/s at 41 k rows, 60 vs 51 at 10 k): occupancy hides the weight-fetch
 // latency better than the 2x weight reuse of the taller tile.  MOBODY_TILE_ROWS=64 selects the tall tile (tuning aid).
 inline int pick_tile_rows(long long rows, int members) {
-  static const int forced = [] { const char* e = getenv("MOBODY_TILE_ROWS"); return e ? atoi(e) : 0; }();
+  static const int forced = tune_int("MOBODY_TILE_ROWS", 0);
   (void)rows; (void)members;
   return forced == 64 ? 64 : 32;
 }

@@ -768,7 +768,7 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
     MB_LAUNCH_OK("k_wgrad_f16");
     return 0;
   }
-  static const int bf_force = [] { const char* e = getenv("MOBODY_WGRAD_BF"); return e ? atoi(e) : -1; }();
+  static const int bf_force = tune_int("MOBODY_WGRAD_BF", -1);
   const bool use_bf = bf_force == 0 ? false : a.prec != 0;
   if (use_bf && a.job[0].ka == HID && a.job[0].nb == HID && a.job[0].wide) {
     static bool once_bf = false;

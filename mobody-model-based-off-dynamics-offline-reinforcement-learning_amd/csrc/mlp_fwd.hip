@@ -153,7 +153,7 @@ static int narrow_tiles(int Np3) { return Np3 == 16 ? 1 : Np3 == 32 ? 2 : 0; }
 int launch_mlp3_fwd_pair(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, hipStream_t stream) {
   if (a.rows <= 0) return launch_mlp3_fwd(b, members_b, ACT_RELU, stream);
   if (b.rows <= 0) return launch_mlp3_fwd(a, members_a, ACT_RELU, stream);
-  static const bool split = [] { const char* e = getenv("MOBODY_NO_FWD_PAIR"); return e && atoi(e) != 0; }();   // tuning aid
+  static const bool split = tune_int("MOBODY_NO_FWD_PAIR", 0) != 0;   // tuning aid (diagnostic build)
   if (split || a.Np3 != b.Np3) {                  // the merged kernel is specialised on one output-layer width
     int rc = launch_mlp3_fwd(a, members_a, ACT_RELU, stream);
     return rc ? rc : launch_mlp3_fwd(b, members_b, ACT_RELU, stream);
@@ -170,7 +170,7 @@ int launch_mlp3_fwd_pair(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs&
 
 template <int ACT>
 static int launch_fwd_act(const Mlp3FwdArgs& a, int members, hipStream_t stream) {
-  static const int shape = [] { const char* e = getenv("MOBODY_FWD_SHAPE"); return e ? atoi(e) : 0; }();   // tuning aid
+  static const int shape = tune_int("MOBODY_FWD_SHAPE", 0);   // tuning aid (diagnostic build)
   if (shape == 8) return launch_fwd_t<ACT, 1, 2, 0>(a, members, stream);
   const bool tall = pick_tile_rows(a.rows, members) == 64;
   const int nt = narrow_tiles(a.Np3);

@@ -1,6 +1,7 @@
 // Argument blocks shared by the training translation units (mlp_bwd.hip, train.hip).
 #pragma once
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "tile.h"

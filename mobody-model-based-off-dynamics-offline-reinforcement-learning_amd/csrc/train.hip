@@ -382,7 +382,7 @@ extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper*
   const Mlp3FwdArgs fb = fwd_args(q_blob, w.Lq, state, S, action, A, Nt, w.qb, 0, 1.f, nullptr, nullptr, nullptr, nullptr, nullptr, qT);
   // Q(s, pi(s)) with the freshly updated critic (:316); dQ/da through the frozen net needs only the ReLU signs
   const Mlp3FwdArgs fp = fwd_args(q_blob, w.Lq, state, S, w.pi, A, N, w.q, 0, 1.f, nullptr, nullptr, nullptr, w.mq1, w.mq2, qT);
-  static const bool split_q = [] { const char* e = getenv("MOBODY_MERGE_ACTOR_Q"); return e && atoi(e) == 0; }();   // tuning aid
+  static const bool split_q = tune_int("MOBODY_MERGE_ACTOR_Q", 1) == 0;   // tuning aid (diagnostic build)
   if (policy_ready && !split_q) {
     rc = fwd_pair(fb, 2, fp, 2, prec, st);                 // both on the same critic: one launch of N + Nt rows (0.384 -> 0.380 ms/step)
   } else {
