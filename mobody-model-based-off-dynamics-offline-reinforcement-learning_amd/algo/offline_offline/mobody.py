@@ -434,8 +434,9 @@ class MOBODY(object):
         par_ok = self.penalty_type != "par" or (dyn is not None and getattr(dyn, "noise_fn", None) is None
                                                 and dyn.rng == "device" and not getattr(dyn.model, "mopo", False))
         adv_ok = not self.config["advantage"] or (self._world() == 1 and self.fused_update and self._v_ws is not None)
-        return (want and self.rng == "device" and par_ok and adv_ok and (self.total_it - 1) % REFRESH_EVERY != 0
-                and not (writer is not None and self.total_it % 5000 == 0))
+        # logging steps run eagerly: every 5000th (losses / value scalars) and, under 'par', every 100th (mobody.py:432-433)
+        logs = writer is not None and (self.total_it % 5000 == 0 or (self.penalty_type == "par" and self.total_it % 100 == 0))
+        return (want and self.rng == "device" and par_ok and adv_ok and (self.total_it - 1) % REFRESH_EVERY != 0 and not logs)
 
     @staticmethod
     def _world():
@@ -609,13 +610,30 @@ class MOBODY(object):
         self._gather([src_replay_buffer, tar_replay_buffer], [ns, nt], tuple(t[:Nt] for t in b))
         if self.penalty_type == "par":                                        # :428-434
             r = self.dynamics.step_device(b[0][:ns], b[1][:ns])
+            if writer is not None and self.total_it % 100 == 0:               # :432-433
+                writer.add_scalar("train/reward_penalty_par", torch.mean((b[2][:ns] - r["next_obs"]) ** 2), global_step=self.total_it)
             ops.par_penalty(b[2][:ns], r["next_obs"], b[3][:ns], cfg["penalty_coef"])
         if (self.total_it - 1) % REFRESH_EVERY == 0:
             self._refresh(src_replay_buffer, tar_replay_buffer, batch_size)
         if nf > 0:                                                            # :523-529
             self._gather([self.fake_replay_buffer], [nf], tuple(t[Nt:] for t in b))
+        log5k = writer is not None and self.total_it % 5000 == 0
+        if log5k and cfg["advantage"]:                    # update_v_function's scalars, BEFORE this step's V update (:236-240)
+            qt = ops.mlp3_forward(self.target_q_funcs.blob, S + A, 1, 2, b[0], b[1]).view(2, N)
+            v0 = ops.mlp3_forward(self.v_func.blob, S, 1, 1, b[0]).view(N)
+            writer.add_scalar("train/adv", (torch.minimum(qt[0], qt[1]) - v0).mean(), self.total_it)
+            writer.add_scalar("train/value", v0.mean(), self.total_it)
         self._update(b, N, Nt)
-        if writer is not None and self.total_it % 5000 == 0:
+        if log5k:
+            if cfg["q_weighted"] and Nt > 0:              # bc_loss's exp_adv (:251-273): Q after this step's critic update, as there
+                qb = ops.mlp3_forward(self.q_funcs.blob, S + A, 1, 2, b[0][:Nt], b[1][:Nt], blob_T=self.q_funcs.blob_T,
+                                      precision=self.precision).view(2, Nt)
+                qb = torch.minimum(qb[0], qb[1])
+                if cfg["advantage"]:
+                    adv = qb - ops.mlp3_forward(self.v_func.blob, S, 1, 1, b[0][:Nt]).view(Nt)
+                else:
+                    adv = qb / qb.abs().mean()
+                writer.add_scalar("train/exp_adv", torch.exp(3.0 * adv).clamp(max=100.0).mean(), self.total_it)
             q_loss, pi_loss, bc_loss = [float(x) for x in self._loss[:3].tolist()]
             writer.add_scalar("train/q_loss", q_loss, self.total_it)
             writer.add_scalar("train/policy_loss", pi_loss, self.total_it)

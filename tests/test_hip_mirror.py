@@ -627,7 +627,9 @@ def test_writer_scalars_on_the_reference_cadence(dev, tmp_path):
     pol.train(src, tar, bs, w, None)
     w.close()
     got = {r[0]: (int(r[1]), float(r[2])) for r in (l.strip().split(",") for l in list(open(w.path))[1:])}
-    assert set(got) == {"train/q_loss", "train/policy_loss", "train/bc_loss", "train/q1", "train/q_behavior", "train/q_policy"}
+    assert set(got) == {"train/q_loss", "train/policy_loss", "train/bc_loss", "train/q1", "train/q_behavior", "train/q_policy",
+                        "train/exp_adv"}
+    assert 0.0 < got["train/exp_adv"][1] <= 100.0
     assert all(step == 5000 for step, _ in got.values())
     q, pi, bc = pol.losses()
     assert (got["train/q_loss"][1], got["train/policy_loss"][1], got["train/bc_loss"][1]) == (q, pi, bc)
