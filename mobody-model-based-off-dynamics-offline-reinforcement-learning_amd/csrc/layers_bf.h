@@ -74,9 +74,9 @@ __device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, 
 // fp32 layer whose output goes to planes instead of the fp32 image.  Returns the tile's scale exponent (planes hold
 // y * 2^e; 0 outside the f16 mode).  `scr`: 8 floats of LDS for the tile maximum (f16 mode).  Optional copies of the
 // activations: gsave (fp32 rows, this tile's base) and gs (fp16 planes for the weight-gradient GEMM); optional sign words.
-template <int ACT, int MT, int PM, int TB, class Between>
+template <int ACT, int MT, int PM, int TB, class Ring, class Between>
 __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* scr, const float* __restrict__ W,
-                                                    const float* __restrict__ b, int Kp, WideRing& ring, Between&& between,
+                                                    const float* __restrict__ b, int Kp, Ring& ring, Between&& between,
                                                     uint32_t* mask = nullptr, bool full = true, int mask_groups = 0,
                                                     int rows_here = 1 << 30, float* gsave = nullptr,
                                                     const PlaneSave& gs = PlaneSave{nullptr, 0, nullptr}) {

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(NTHREADS, (MT == 1 && MASK == 1) ? 3 : 2) void k_ml
   float* scr = reinterpret_cast<float*>(reinterpret_cast<char*>(Xs) + split_scr_offset<PMX, TB>());   // tile maximum (f16 mode)
 
   TR(0);
-  WideRing ring;
+  // (split modes: the ring only serves the K = Np3 GEMM, two to four chunks -- three stages keep the kernel at 128 registers)
+  WideRingT<(PM > 0 ? 3 : WIDE_RING)> ring;
   wide_prefetch(w3t, a.Np3, ring);                // weight fragments travel while the seed rows are fetched
   if (a.seed.mode == 0) tile_load(Xs, 0, a.dz3 + ((long long)m * a.rows + row0) * a.Np3, a.Np3, a.Np3, 0, rows_here, TB);
   else bwd_seed(a, Xs, red, m, row0, rows_here, TB);

@@ -8,8 +8,11 @@
 #include "common.h"
 #include "layers_bf.h"
 
+#ifndef FWD_L1_RING
+#define FWD_L1_RING 3
+#endif
 #ifndef FWD_F16_WAVES
-#define FWD_F16_WAVES 2
+#define FWD_F16_WAVES 4
 #endif
 namespace mobody {
 
@@ -26,7 +29,7 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
   const float* w3 = a.w3 + m * a.sw3;
   const float* b3 = a.b3 + m * a.sb3;
   TR(0);
-  WideRing ring;
+  WideRingT<FWD_L1_RING> ring;                  // layer 1 is K = 24 .. 120: a short ring keeps the kernel at 128 registers
   wide_prefetch(w1, a.Kp1, ring);
   int c0 = 0;
 #pragma unroll

@@ -83,7 +83,9 @@ __host__ __device__ inline long long wide_idx(int k, int n) { return ((long long
 // ~0.9 us (~2000 cycles): throughput per wave = bytes in flight / latency, so 4 chunks (2 KB per wave) are
 // kept in flight.  (With 2 chunks of 4-byte loads the 640-workgroup twin-Q forward ran at 35 % MFMA busy.)
 constexpr int WIDE_RING = 5;
-struct WideRing { f32x4 r[WIDE_RING][2]; };
+template <int R>
+struct WideRingT { f32x4 r[R][2]; };
+using WideRing = WideRingT<WIDE_RING>;
 
 __device__ __forceinline__ void wide_ldb(const float* __restrict__ W, int Kp, int c, f32x4 (&b)[2]) {
   const int lane = lane_id();
@@ -99,18 +101,18 @@ __device__ __forceinline__ void wide_ldb(const float* __restrict__ W, int Kp, in
 // Request the first WIDE_RING-1 chunks of W.  Called as early as the data dependences allow (before the input
 // tile is in LDS, before the previous layer's epilogue): a layer that starts with a cold ring puts one L2/HBM round
 // trip (~1 us) in front of its first MFMA, and in a single-generation launch every workgroup does so at once.
-__device__ __forceinline__ void wide_prefetch(const float* __restrict__ W, int Kp, WideRing& ring) {
+template <int R>
+__device__ __forceinline__ void wide_prefetch(const float* __restrict__ W, int Kp, WideRingT<R>& ring) {
   const int nch = Kp >> 3;
 #pragma unroll
-  for (int j = 0; j < WIDE_RING - 1; ++j) wide_ldb(W, Kp, min(j, nch - 1), ring.r[j]);   // unconditional (see wide_gemm)
+  for (int j = 0; j < R - 1; ++j) wide_ldb(W, Kp, min(j, nch - 1), ring.r[j]);   // unconditional (see wide_gemm)
   __builtin_amdgcn_sched_barrier(0);
 }
 
 // `ring` must hold wide_prefetch(W, Kp).
-template <int MT>
+template <int MT, int R>
 __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const float* __restrict__ W, int Kp,
-                                          f32x16 (&acc)[MT][2], WideRing& ring) {
-  constexpr int R = WIDE_RING;
+                                          f32x16 (&acc)[MT][2], WideRingT<R>& ring) {
   const int lane = lane_id();
   const int i = lane & 31, h = lane >> 5;
   const int kh = Kp >> 1;                       // K range of this lane half, multiple of 4
@@ -155,7 +157,7 @@ __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const fl
                                           f32x16 (&acc)[MT][2]) {
   WideRing ring;
   wide_prefetch(W, Kp, ring);
-  wide_gemm<MT>(Xs, W, Kp, acc, ring);
+  wide_gemm<MT, WIDE_RING>(Xs, W, Kp, acc, ring);
 }
 
 // Visit every accumulator element of a wide result: f(row 0..32*MT-1, col 0..255, value).
