@@ -8,6 +8,9 @@
 #include "common.h"
 #include "layers_bf.h"
 
+#ifndef BF_RG_DEFAULT
+#define BF_RG_DEFAULT 1
+#endif
 #ifndef FWD_L1_RING
 #define FWD_L1_RING 3
 #endif
@@ -128,7 +131,7 @@ static int launch_bf_nt(const Mlp3FwdArgs& a, int ma, const Mlp3FwdArgs& b, int 
 int launch_mlp3_fwd_bf(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, int act, int prec, hipStream_t st) {
   // row groups per workgroup: 1 = 32-row tiles of 4 waves (measured best: twin-Q forward at 10 240 rows 28.8 us in bf16x3
   // against 41.5 us with two row groups sharing each weight fragment, 39.5 us in fp32); MOBODY_BF_RG=2 is a tuning aid
-  static const int rg = tune_int("MOBODY_BF_RG", 1);
+  static const int rg = tune_int("MOBODY_BF_RG", BF_RG_DEFAULT);
   if (a.rows <= 0 && b.rows <= 0) return 0;
   Mlp3FwdArgs x = a, y = b; int mx = members_a, my = members_b;
   if (x.rows <= 0) { x = b; mx = members_b; y.rows = 0; my = 0; }

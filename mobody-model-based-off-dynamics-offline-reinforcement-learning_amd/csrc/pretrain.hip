@@ -687,6 +687,7 @@ static AdamTarget pre_adam_target(float* p, float* pT, float* m, float* v, int64
   a.c.step_size = (float)((double)lr / bc1); a.c.bc2_sqrt = (float)sqrt(bc2); a.c.eps = 1e-8f;
   a.c.tau = -1.f; a.c.one_minus_tau = 0.f; a.c.gscale = grad_scale;
   a.t_dev = (const long long*)t_dev; a.lr = lr; a.on = 1;
+  a.precision = -1;                               // pre-training is exact fp32: the W2 planes of its T blob are never read
   return a;
 }
 struct PreOpt {             // fused optimizer step (single GPU): Adam state and step counts; on = 0 -> gradients only

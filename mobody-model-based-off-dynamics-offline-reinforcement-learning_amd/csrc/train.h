@@ -151,7 +151,8 @@ struct AdamTarget {
   float lr;
   int on;                                   // k_grad_reduce only: 0 = just write the gradient
   long long* bump;                          // k_grad_reduce only: device word incremented by one thread (not t_dev), or null
-  int precision;                            // format of the W2 planes kept in blob_T / target_T (write_w2_planes)
+  int precision;                            // format of the W2 planes kept in blob_T / target_T (write_w2_planes); < 0: no planes
+                                            // (dynamics pre-training runs exact fp32: six scattered 2-byte stores per W2 element saved)
 };
 
 // Bias corrections of a device-side step count (graph replay), formed ONCE per workgroup in double: thread 0 computes,
@@ -194,7 +195,7 @@ __device__ __forceinline__ void adam_element(const AdamTarget& a, const MobodyMl
     const long long o = j - (long long)mem * L.member_floats;
     const long long ti = t_blob_index(L, o);
     if (ti >= 0 && a.blob_T != nullptr) a.blob_T[(long long)mem * L.t_member_floats + ti] = pj;
-    if (o >= L.w2 && o < L.b2) {                     // a W2 element (wide storage): its planes
+    if (o >= L.w2 && o < L.b2 && a.precision >= 0) {  // a W2 element (wide storage): its planes (precision < 0: nobody streams them)
       const long long oo = o - L.w2, g = oo >> 2;
       const int k = (int)(g / HID) * 4 + (int)(oo & 3), n = (int)(g % HID);
       if (a.blob_T != nullptr) write_w2_planes(a.blob_T + (long long)mem * L.t_member_floats, L, k, n, pj, a.precision);
