@@ -93,12 +93,16 @@ __global__ __launch_bounds__(256) void k_gather_rows(GatherArgs a) {
     const long long src = gather_src(a, r, k);
     mine = a.bufs[k].state + src * a.bufs[k].pitch;
   }
-  float4 v[P][NQ];
+  // (plain vector types and global-address-space pointers: with HIP's float4 struct and a pointer rebuilt from two shuffled
+  //  words the compiler emitted flat loads and kept the rows in SCRATCH memory -- 131 us per million rows instead of 85)
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef const __attribute__((address_space(1))) v4f* gptr_t;
+  v4f v[P][NQ];
 #pragma unroll
   for (int p = 0; p < P; ++p) {
     const unsigned long long up = (unsigned long long)mine;
     const unsigned lo = (unsigned)__shfl((int)(unsigned)up, (threadIdx.x & 48) + p, 64), hi = (unsigned)__shfl((int)(unsigned)(up >> 32), (threadIdx.x & 48) + p, 64);
-    const float4* rp = reinterpret_cast<const float4*>(((unsigned long long)hi << 32) | lo);
+    gptr_t rp = (gptr_t)(((unsigned long long)hi << 32) | lo);
 #pragma unroll
     for (int j = 0; j < NQ; ++j) v[p][j] = rp[min(lane + 16 * j, nq - 1)];
   }
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(GatherArgs a) {
   for (int p = 0; p < P; ++p)
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
-      if (lane + 16 * j < nq) reinterpret_cast<float4*>(stage + (ROWS_WG * p + g) * WS)[lane + 16 * j] = v[p][j];
+      if (lane + 16 * j < nq) reinterpret_cast<v4f*>(stage + (ROWS_WG * p + g) * WS)[lane + 16 * j] = v[p][j];
   __syncthreads();
   const int rows = (int)min((long long)ROWS, N - row0);
   stage_to_batch(stage, WS, 0, S, rows, a.state + row0 * S);
