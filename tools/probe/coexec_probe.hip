@@ -55,6 +55,35 @@ __device__ __forceinline__ void role_epi(int iters, float* out, char* lds) {
   out[threadIdx.x] = s;
 }
 
+__device__ __forceinline__ void role_mix(int iters, float* out, char* lds) {
+  f16x8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(0.001f * (threadIdx.x + j)); b[j] = (_Float16)(0.002f * (threadIdx.x ^ j)); }
+  f32x16 c0 = {0}, c1 = {0};
+  float x[16];
+  for (int j = 0; j < 16; ++j) x[j] = 0.5f + 0.001f * (threadIdx.x + j);
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c1, 0, 0, 0);
+      s16x4 v0, v1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float y = fmaxf(x[4 * g + j] + 0.25f, 0.f) * 1.5f;
+        const _Float16 t0 = (_Float16)y; const _Float16 t1 = (_Float16)(y - (float)t0);
+        v0[j] = __builtin_bit_cast(short, t0); v1[j] = __builtin_bit_cast(short, t1);
+        x[4 * g + j] = y * 0.37f;
+      }
+      *reinterpret_cast<s16x4*>(lds + ((threadIdx.x & 255) * 64 + g * 16)) = v0;
+      *reinterpret_cast<s16x4*>(lds + ((threadIdx.x & 255) * 64 + g * 16 + 8)) = v1;
+    }
+  }
+  float s = 0; for (int j = 0; j < 16; ++j) s += x[j];
+  out[threadIdx.x] = c0[0] + c1[3] + s;
+}
+
 __global__ __launch_bounds__(512, 2) void k(int roleA, int roleB, int itA, int itB, float* out, long long* cyc, int prioB) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int grp = threadIdx.x >> 8;
@@ -64,6 +93,7 @@ __global__ __launch_bounds__(512, 2) void k(int roleA, int roleB, int itA, int i
   if (role == 1) role_mfma(it, out + blockIdx.x * 512);
   else if (role == 2) role_valu(it, out + blockIdx.x * 512);
   else if (role == 3) role_epi(it, out + blockIdx.x * 512, lds + grp * 16384);
+  else if (role == 5) role_mix(it, out + blockIdx.x * 512, lds + grp * 16384);
   const long long t1 = __builtin_amdgcn_s_memtime();
   if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
@@ -95,6 +125,10 @@ int main() {
   run(1, 2, IM, IV, "mfma + valu");
   run(1, 3, IM, IE, "mfma + epilogue-mix");
   run(3, 3, IE, IE, "epilogue-mix x2");
+  run(5, 0, IM, 0, "ONE wave: 16 mfma + epilogue-mix per iter");
+  run(1, 0, IM, 0, "mfma alone (16 per iter, same count)");
+  run(3, 0, IM, 0, "epilogue-mix alone (same count)");
+  run(5, 5, IM, IM, "mix x2 waves per SIMD");
   run(1, 2, IM, IV, "mfma + valu(prio1)", 1);
   run(1, 2, IM, IV, "mfma + valu(prio3)", 3);
   run(1, 3, IM, IE, "mfma + epi-mix(prio1)", 1);

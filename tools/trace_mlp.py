@@ -26,7 +26,8 @@ ws = ops.train_workspace(dims, dev)
 
 def run():
     if mode == "fwd":
-        ops.mlp3_forward(eng.q, S + A, 1, 2, b[0], b[1], save=True, blob_T=eng.q_T, precision=cfg['mfma'])
+        # (the pipelined f16x2 kernel carries no fp32 copy of layer 1: traced without the saves)
+        ops.mlp3_forward(eng.q, S + A, 1, 2, b[0], b[1], save=not int(os.environ.get('PIPE_MT', '0')), blob_T=eng.q_T, precision=cfg['mfma'])
     elif mode == "critic":
         ops.critic_step(dims, hyp, eng.actor, eng.q, eng.q_T, eng.qt, b, eng.gq, eng.loss[0:1], ws, actor_blob_T=eng.actor_T, qtarg_blob_T=eng.qt_T)
     else:
@@ -46,6 +47,11 @@ lib = _lib.load()
 assert lib.mobody_debug_trace(buf, nb * 8) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(nb, 8).astype(np.int64)
 FWD = ["start", "input in LDS", "layer1 done", "layer2 gemm done", "layer2 done", "end"]
+PIPE = int(os.environ.get("PIPE_MT", "0"))        # trace of k_mlp3_fwd_pipe built with -DFWD_PIPE_MT=PIPE (mode fwd)
+if PIPE and mode == "fwd":
+    nb = ((N + 64 * PIPE - 1) // (64 * PIPE)) * 2
+    t = t[:nb]
+    FWD = ["start", "inputs in LDS", "layer1 P,Q + maxima", "epi1(P)", "gemm2(P) | epi1(Q)", "gemm2(Q) | epi2(P)", "epi2(Q)", "end"]
 BWD = ["start", "seed in LDS", "W3T gemm done", "mask epi 1 done", "W2T gemm done", "mask epi 2 done", "end (dX)"]
 
 
@@ -60,7 +66,7 @@ def report(title, tt, names):
 
 if mode == "fwd":
     report("twin-Q forward", t, FWD)
-    if cfg["mfma"] != "f32":                      # slots 6, 7: layer-1 GEMM done / layer-1 epilogue (plane split + h1 save) done
+    if cfg["mfma"] != "f32" and not PIPE:         # slots 6, 7: layer-1 GEMM done / layer-1 epilogue (plane split + h1 save) done
         us = (t - t[:, 0].min()) / 100.0
         print(f"  layer 1 (split-precision tile): gemm done {us[:, 6].mean():.2f}, epilogue done {us[:, 7].mean():.2f}, "
               f"barrier passed {us[:, 2].mean():.2f}")
