@@ -339,8 +339,8 @@ def pretrain_flops(S, A, b):
 
 def bench_pretrain(args, dev, world, rank):
     """`--config pretrain`: optimizer steps per second of MOBODYEnsembleDynamics.learn (mobody_dynamics.py:594-653) at the
-    reference's batch (256 rows x 7 members), walker2d shapes, device-Philox noise, the mirror's HIP-graph replay of the
-    22-launch step; K timed steps between barriers.  Single GPU (the data-parallel form shards the batch rows)."""
+    reference's batch (256 rows x 7 members), walker2d shapes, device-Philox noise, the mirror's eager two-stream step
+    (config train_graph = 1: its HIP-graph replay); K timed steps between barriers.  Single GPU (the data-parallel form shards the batch rows)."""
     import numpy as np
     import torch
     from mobody_amd import _lib, engine, synthetic
@@ -350,9 +350,12 @@ def bench_pretrain(args, dev, world, rank):
     assert world == 1, "--config pretrain is a single-GPU measurement"
     S, A, b, task = 17, 6, args.batch_size or 256, "walker2d-medium-v2"
     steps, warm = args.steps, max(args.warmup, 3)
-    cfg = engine.default_config(S, A, no_vae=0, inverse_sep_reward_loss=0, train_together=0, train_with_src_threshold=1, dynamics_lr=1e-3)
+    cfg = engine.default_config(S, A, no_vae=0, inverse_sep_reward_loss=0, train_together=0, train_with_src_threshold=1, dynamics_lr=1e-3,
+                                mfma=args.mfma)
     m = MOBODYModule(S, A, 256, 7, 5, device=dev, config=cfg)
     dyn = MOBODYEnsembleDynamics(cfg, m, None, None, get_termination_fn(task), penalty_coef=0.1, rng="device", seed=1)
+    f16 = dyn.train_precision == 4                      # pre-training follows --mfma when it is f16x2, else exact fp32 MFMA
+    graph = bool(dyn.train_graph)                       # (off by default: the eager step measured faster than its graph replay)
     g = torch.Generator().manual_seed(0)
     mu = torch.from_numpy(synthetic.alive_mean(task, S))
     n = 200000
@@ -360,10 +363,10 @@ def bench_pretrain(args, dev, world, rank):
             (mu + 0.1 * torch.randn(n, S, generator=g)).to(dev), torch.randn(n, 1, generator=g).to(dev)]
     idx = torch.randint(n, (7, steps * b), generator=g).to(device=dev, dtype=torch.int32).contiguous()
     dyn._learn_indexed(True, data, idx[:, :warm * b].contiguous(), b)
-    dyn._learn_indexed(True, data, idx, b)                # captures the graph of this index matrix
+    dyn._learn_indexed(True, data, idx, b)                # (train_graph = 1: captures the graph of this index matrix)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    stats = dyn._learn_indexed(True, data, idx, b)        # K optimizer steps (graph replays)
+    stats = dyn._learn_indexed(True, data, idx, b)        # K optimizer steps
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     # per-family times of the same step, eager (event pairs are not part of a captured graph)
@@ -384,16 +387,18 @@ def bench_pretrain(args, dev, world, rank):
     roofline = dict(kernel=dom, bound="mfma", achieved=per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                     peak=PEAK_F32_TFLOPS, unit="TFLOP/s", traffic=None, avg_launch_ms=avg_ms,
                     launches_per_step=d["launches_per_step"], flops_per_launch=per_launch,
-                    peak_note="dense fp32-input MFMA peak (the pre-training kernels run exact fp32 MFMA)",
+                    peak_note="dense fp32-input MFMA peak" + (" (f16x2: the 256 x 256 layers run as three fp16 MFMAs per fp32 product; "
+                                                              "priced against the fp32 peak the first / last layers still use)" if f16 else
+                                                              " (the pre-training kernels run exact fp32 MFMA)"),
                     traffic_note="null: no PMC pass for this configuration")
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
     out = {"metric": "dynamics pre-training optimizer steps/sec (MOBODYEnsembleDynamics.learn, the step before the hot path)",
            "value": steps / dt, "unit": "optimizer steps/s", "n_gpus": 1, "steps": steps, "warmup": warm,
-           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-           "data": "synthetic",
+           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f16x2 split (fp32-grade), fp32 accumulate" if f16 else "f32", "mfma": "f16x2" if f16 else "f32", "data": "synthetic",
            "config": {"workload": f"pretrain: walker2d shapes (S={S} A={A}), {b} rows x 7 members per optimizer step, target-domain batches, "
-                                  "device-Philox reparameterisation noise, HIP-graph replay", "name": "pretrain", "rows_per_step": 7 * b,
-                      "parallelism": "dp1", "hip_graph": True},
+                                  "device-Philox reparameterisation noise, " + ("HIP-graph replay" if graph else "eager launches (two streams)"),
+                      "name": "pretrain", "rows_per_step": 7 * b, "parallelism": "dp1", "hip_graph": graph},
            "samples_per_sec": steps * b * 7 / dt, "useful_tflops": fl * steps / dt / 1e12,
            "frac_f32_mfma_peak_whole_step": fl * steps / dt / (PEAK_F32_TFLOPS * 1e12),
            "roofline": roofline, "kernels": fam, "mean_losses": list(stats)}

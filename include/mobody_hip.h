@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MOBODY_ABI_VERSION 4
+#define MOBODY_ABI_VERSION 5
 #define MOBODY_E_ARG (-1)      /* bad argument (dims, null pointer, unsupported size) */
 #define MOBODY_E_LAUNCH (-2)   /* hipLaunch / runtime error */
 #define MOBODY_E_UNSUPPORTED (-3)
@@ -382,7 +382,10 @@ typedef struct MobodyPretrainLayout {
   int64_t t_off_enc, t_off_tr, t_off_rw, t_total_floats;      /* T blob */
 } MobodyPretrainLayout;
 int mobody_pretrain_layout(int S, int A, MobodyPretrainLayout* out);
-int mobody_pretrain_transpose(int S, int A, const float* blob, float* blob_T, void* stream);
+/* `precision` of the four pre-training entry points: 0 = exact fp32 MFMA, 4 = "f16x2" (the 256 x 256 layers of the three
+ * 7-member nets on the split core, h1 / dz2 handed to the weight-gradient GEMM as fp16 planes; other modes are refused).
+ * The T blob carries the W2 / W2^T planes of the mode it was built for; Adam keeps them current. */
+int mobody_pretrain_transpose(int S, int A, const float* blob, float* blob_T, int precision, void* stream);
 int64_t mobody_pretrain_workspace(int S, int A, int64_t b);
 
 /* Bootstrap gather of one batch (learn() slices train_obss[:, k*bs:(k+1)*bs] of the per-member bootstrapped arrays,
@@ -404,21 +407,23 @@ int mobody_pretrain_gather(const float* state, const float* action, const float*
 int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, int use_trg, float encoder_loss_coef,
                           const float* blob, const float* blob_T, const float* xenc, const float* act, const float* rew,
                           const float* noise6, const float* noise7, uint32_t seed, uint32_t call, float* grad,
-                          float* loss_out, float* workspace, void* stream);
+                          float* loss_out, float* workspace, int precision, void* stream);
 
 /* Single-GPU form of mobody_pretrain_grads + mobody_pretrain_adam: every gradient reduction applies the Adam step of the
  * elements it has just reduced (no gradient blob, four launches fewer).  t_dev (nullable): DEVICE int64[2] = {t_main,
- * t_za} read instead of the host counts; call_dev (nullable): DEVICE int64 word added to `call` -- both for graph replay. */
+ * t_za} read instead of the host counts; call_dev (nullable): DEVICE int64 word added to `call` -- both for graph replay.
+ * loss_acc (nullable): DEVICE float[5], loss_acc += loss_out in the step's last launch (learn()'s running sums, :630-650). */
 int mobody_pretrain_update(int S, int A, int64_t b, int use_trg, float encoder_loss_coef, float* blob, float* blob_T,
                            const float* xenc, const float* act, const float* rew, const float* noise6, const float* noise7,
                            uint32_t seed, uint32_t call, const int64_t* call_dev, float* m, float* v, int64_t t_main,
-                           int64_t t_za, const int64_t* t_dev, float lr, float* loss_out, float* workspace, void* stream);
+                           int64_t t_za, const int64_t* t_dev, float lr, float* loss_out, float* loss_acc, float* workspace,
+                           int precision, void* stream);
 
 /* torch.optim.Adam step on the blob (and its T blob): the three MLP regions use the 1-based step count t_main, the
  * action encoder of this step's domain t_za; the other action encoder is skipped (its .grad is None in the reference,
  * so its Adam state does not advance). */
 int mobody_pretrain_adam(int S, int A, int use_trg, float* blob, float* blob_T, const float* grad, float* m, float* v,
-                         int64_t t_main, int64_t t_za, float lr, float grad_scale, void* stream);
+                         int64_t t_main, int64_t t_za, float lr, float grad_scale, int precision, void* stream);
 
 /* validate() (:1113-1140) on an inference blob (mobody_dyn_layout): out[0..6] = per-member mean_{b,d}(mean_e - s')^2,
  * out[7..13] = per-member mean_b (r_mu_e(s, a, mean_e) - r)^2.  Workspace floats: mobody_dyn_validate_workspace. */

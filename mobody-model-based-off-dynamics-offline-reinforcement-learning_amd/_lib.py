@@ -116,14 +116,14 @@ PROTOTYPES = {
     "mobody_dara_penalty": (C.c_int, [vp, vp, i64, f32, vp, vp, vp]),
     "mobody_mlp_transpose": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "mobody_pretrain_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(MobodyPretrainLayout)]),
-    "mobody_pretrain_transpose": (C.c_int, [C.c_int, C.c_int, vp, vp, vp]),
+    "mobody_pretrain_transpose": (C.c_int, [C.c_int, C.c_int, vp, vp, C.c_int, vp]),
     "mobody_pretrain_workspace": (i64, [C.c_int, C.c_int, i64]),
     "mobody_pretrain_gather": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, vp, i64, C.c_int, C.c_int, vp, vp, vp, vp]),
     "mobody_pretrain_update": (C.c_int, [C.c_int, C.c_int, i64, C.c_int, f32, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp,
-                                         vp, i64, i64, vp, f32, vp, vp, vp]),
+                                         vp, i64, i64, vp, f32, vp, vp, vp, C.c_int, vp]),
     "mobody_pretrain_grads": (C.c_int, [C.c_int, C.c_int, i64, i64, C.c_int, f32, vp, vp, vp, vp, vp, vp, vp, u32, u32,
-                                        vp, vp, vp, vp]),
-    "mobody_pretrain_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, i64, i64, f32, f32, vp]),
+                                        vp, vp, vp, C.c_int, vp]),
+    "mobody_pretrain_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, i64, i64, f32, f32, C.c_int, vp]),
     "mobody_dyn_validate_workspace": (i64, [C.c_int, C.c_int, i64]),
     "mobody_dyn_validate": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp]),
 }
@@ -147,7 +147,7 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.mobody_abi_version() != 4:
+    if lib.mobody_abi_version() != 5:
         raise ImportError("libmobody_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -60,12 +60,17 @@ class MOBODYEnsembleDynamics(object):
         self.encode_trg_diff = getattr(model, "encode_trg_diff", 0)
         self.rng, self.seed = rng, int(seed)
         self.precision = ops.prec_id(str(config.get("mfma", ops.default_mfma())))     # MFMA mode of step(): 0 exact fp32 | bf16 / bf16x2 / bf16x3
+        # pre-training follows the mode when it is the fp32-grade "f16x2", and stays on exact fp32 MFMA under the bf16 modes
+        self.train_precision = 4 if self.precision == 4 else 0
         self._calls = 0
         self.noise_fn = None          # optional hook: noise_fn((7, B, S)) -> unit normals (tests)
         self.train_noise_fn = None    # optional hook: b -> (noise6[6,7,b,16], noise7[7,b,S]) device tensors (tests)
         self._ws = None
-        self._pre_ws_by_b, self._train_calls = {}, 0
-        self.train_graph = int(config.get("train_graph", 1))   # replay full pre-training batches as one HIP graph (1 GPU, device noise)
+        self._pre_ws_by_b, self._pre_bufs_by_b, self._train_calls = {}, {}, 0
+        # 1: replay full pre-training batches as one HIP graph (1 GPU, device noise).  Off by default since round 3: the step is
+        # ~20 launches of 5-20 us, the host's eager launches stay ahead of the GPU, and a graph replay measured SLOWER (0.260 ms
+        # against 0.237 per step at 256 rows x 7 members; with the side stream 0.266 against 0.228) -- for a host that cannot.
+        self.train_graph = int(config.get("train_graph", 0))
         self._pre_graphs = {}
         self._pre_ctr = torch.zeros(4, dtype=torch.int64, device=model.device)
         self._pre_acc = torch.zeros(5, dtype=torch.float32, device=model.device)
@@ -145,7 +150,7 @@ class MOBODYEnsembleDynamics(object):
         """One optimizer step on the rows already laid out as the kernels want them (zero_grad, backward, Adam.step).
         Data parallel: this rank holds rows [lo_rel, lo_rel + b) of the batch's b_global rows."""
         m = self.model
-        st = m.train_state()
+        st = m.train_state(self.train_precision)
         S, A = m.obs_dim, m.action_dim
         ws = self._ws_for(max(b, 1))
         self._train_calls += 1
@@ -158,7 +163,8 @@ class MOBODYEnsembleDynamics(object):
         if b > 0:
             ops.pretrain_grads(S, A, b, use_trg, self.encoder_loss_coef, st["blob"], st["blob_T"], xenc, act, rew, st["grad"],
                                self._pre_loss, ws, noise6=n6, noise7=n7,
-                               seed=(self.seed + 77 + dp.rank_salt()) & 0xFFFFFFFF, call=self._train_calls, b_global=b_global)
+                               seed=(self.seed + 77 + dp.rank_salt()) & 0xFFFFFFFF, call=self._train_calls, b_global=b_global,
+                               precision=self.train_precision)
         else:                                             # data parallel: this rank has no row of a ragged last batch
             st["grad"].zero_(); self._pre_loss.zero_()
         if world > 1:
@@ -166,19 +172,29 @@ class MOBODYEnsembleDynamics(object):
             torch.distributed.all_reduce(self._pre_loss)
         st["t_main"] += 1; st["t_za"][bool(use_trg)] += 1
         ops.pretrain_adam(S, A, use_trg, st["blob"], st["blob_T"], st["grad"], st["m"], st["v"], st["t_main"],
-                          st["t_za"][bool(use_trg)], self._lr())
+                          st["t_za"][bool(use_trg)], self._lr(), precision=self.train_precision)
         m.mark_trained()
         return self._pre_loss
+
+    def _gather_bufs(self, b):
+        """The batch tensors of the bootstrap gather, kept per batch size (an eager pass would allocate three per step)."""
+        if b not in self._pre_bufs_by_b:
+            m, dev = self.model, self.model.device
+            self._pre_bufs_by_b[b] = (torch.empty(7, 2 * b, m.obs_dim, dtype=torch.float32, device=dev),
+                                      torch.empty(7, b, m.action_dim, dtype=torch.float32, device=dev),
+                                      torch.empty(7, b, dtype=torch.float32, device=dev))
+        return self._pre_bufs_by_b[b]
 
     def _ws_for(self, b):
         if b not in self._pre_ws_by_b:
             self._pre_ws_by_b[b] = ops.pretrain_workspace(self.model.obs_dim, self.model.action_dim, b, self.model.device)
         return self._pre_ws_by_b[b]
 
-    def _learn_batch_fused(self, use_trg, xenc, act, rew, b):
-        """Single-GPU form of _learn_batch: the gradient reductions apply Adam themselves (mobody_pretrain_update)."""
+    def _learn_batch_fused(self, use_trg, xenc, act, rew, b, acc=None):
+        """Single-GPU form of _learn_batch: the gradient reductions apply Adam themselves (mobody_pretrain_update); `acc`
+        (device float[5]): the step's last launch adds the loss vector onto it (no launch of its own for learn()'s sums)."""
         m = self.model
-        st = m.train_state()
+        st = m.train_state(self.train_precision)
         S, A = m.obs_dim, m.action_dim
         ws = self._ws_for(b)
         self._train_calls += 1
@@ -188,23 +204,24 @@ class MOBODYEnsembleDynamics(object):
         st["t_main"] += 1; st["t_za"][bool(use_trg)] += 1
         ops.pretrain_update(S, A, b, use_trg, self.encoder_loss_coef, st["blob"], st["blob_T"], xenc, act, rew, st["m"], st["v"],
                             st["t_main"], st["t_za"][bool(use_trg)], self._lr(), self._pre_loss, ws, noise6=n6,
-                            noise7=n7, seed=(self.seed + 77) & 0xFFFFFFFF, call=self._train_calls)
+                            noise7=n7, seed=(self.seed + 77) & 0xFFFFFFFF, call=self._train_calls, precision=self.train_precision,
+                            loss_acc=acc)
         m.mark_trained()
-        return self._pre_loss
+        return None if acc is not None else self._pre_loss
 
     def _learn_graph(self, use_trg, data, idx, batch_size, n_full):
         """`n_full` full batches of one pass as replays of ONE captured HIP graph (gather + forward + backward + fused Adam,
         ~22 launches): the batch offset into the bootstrap matrix, the noise call id and the Adam step counts live in
         device words that the graph advances itself.  Device-RNG noise only.  Returns the summed loss vector."""
         m = self.model
-        st = m.train_state()
+        st = m.train_state(self.train_precision)
         S, A, b, dev = m.obs_dim, m.action_dim, batch_size, m.device
         d = bool(use_trg)
         ws = self._ws_for(b)
         # every pointer and scalar the captured launches bake in: a graph replayed after any of them moved (a reloaded model,
         # a second train() call, a changed learning rate) would read freed memory or the old constant without any error
         key = (d, b, idx.shape[1], idx.data_ptr(), ws.data_ptr(), self._pre_ctr.data_ptr(), self._pre_acc.data_ptr(),
-               self._pre_loss.data_ptr(), float(self._lr()), float(self.encoder_loss_coef), int(self.seed)) \
+               self._pre_loss.data_ptr(), float(self._lr()), float(self.encoder_loss_coef), int(self.seed), self.train_precision) \
             + tuple(t.data_ptr() for t in data) + tuple(st[k].data_ptr() for k in ("blob", "blob_T", "m", "v"))
         c = self._pre_ctr                                  # [batch index, call, t_main, t_za]: one launch advances all four
         c.copy_(torch.tensor([-1, self._train_calls, st["t_main"], st["t_za"][d]], dtype=torch.int64), non_blocking=False)
@@ -218,8 +235,8 @@ class MOBODYEnsembleDynamics(object):
                 ops.pretrain_gather(data[0], data[1], data[2], data[3], idx, 0, b, out=bufs, start_dev=c[0:1])
                 ops.pretrain_update(S, A, b, d, self.encoder_loss_coef, st["blob"], st["blob_T"], bufs[0], bufs[1], bufs[2],
                                     st["m"], st["v"], 1, 1, self._lr(), self._pre_loss, ws,
-                                    seed=(self.seed + 77) & 0xFFFFFFFF, call=0, call_dev=c[1:2], t_dev=c[2:4])
-                self._pre_acc.add_(self._pre_loss)
+                                    seed=(self.seed + 77) & 0xFFFFFFFF, call=0, call_dev=c[1:2], t_dev=c[2:4],
+                                    precision=self.train_precision, loss_acc=self._pre_acc)
 
             for k in [k for k in self._pre_graphs if k[:2] == key[:2]]:     # a stale graph of this domain / batch size
                 del self._pre_graphs[k]
@@ -249,7 +266,9 @@ class MOBODYEnsembleDynamics(object):
         n_batch = int(np.ceil(n / batch_size))
         for k in range(n_batch):
             self.total_steps = getattr(self, "total_steps", 0) + 1
-            acc += step(k * batch_size, min(batch_size, n - k * batch_size))
+            r = step(k * batch_size, min(batch_size, n - k * batch_size), acc)
+            if r is not None:                             # (None: the step's own last launch accumulated onto `acc`)
+                acc += r
         return tuple(float(x) for x in (acc / max(n_batch, 1)).tolist())
 
     def _shard(self, start, rows):
@@ -267,7 +286,7 @@ class MOBODYEnsembleDynamics(object):
         f = lambda x: torch.as_tensor(x, dtype=torch.float32).to(dev)
         s, a, s2, r = f(train_obss), f(train_actions), f(train_next_obss), f(train_rewards).reshape(7, -1)
 
-        def step(start, rows):
+        def step(start, rows, acc=None):
             lo, b = self._shard(start, rows)
             sl = slice(lo, lo + b)
             xenc = torch.cat([s[:, sl], s2[:, sl]], 1).contiguous()
@@ -281,13 +300,13 @@ class MOBODYEnsembleDynamics(object):
         epoch and ships each batch over PCIe, :604-612)."""
         world, _ = self._world()
 
-        def step(start, rows):
+        def step(start, rows, acc=None):
             lo, b = self._shard(start, rows)
             if b == 0:
                 return self._learn_batch(use_trg, None, None, None, 0, rows, lo - start)
-            xenc, act, rew = ops.pretrain_gather(data[0], data[1], data[2], data[3], idx, lo, b)
+            xenc, act, rew = ops.pretrain_gather(data[0], data[1], data[2], data[3], idx, lo, b, out=self._gather_bufs(b))
             if world == 1:
-                return self._learn_batch_fused(use_trg, xenc, act, rew, b)
+                return self._learn_batch_fused(use_trg, xenc, act, rew, b, acc)
             return self._learn_batch(use_trg, xenc, act, rew, b, rows, lo - start)
 
         n = idx.shape[1]

@@ -153,16 +153,21 @@ class MOBODYModule(object):
             self._p[name + ".saved_bias"][idx] = self._p[name + ".bias"][idx]
 
     # ---- training blob (dynamics pre-training) ----
-    def train_state(self):
-        """dict(blob, blob_T, grad, m, v, t_main, t_za={False: .., True: ..}) of the packed training copy."""
+    def train_state(self, precision=None):
+        """dict(blob, blob_T, grad, m, v, t_main, t_za={False: .., True: ..}, prec) of the packed training copy; `precision`
+        (0 exact fp32 | 4 f16x2; None = leave as is) = the mode of the coming optimizer steps: the T blob carries that mode's W2 planes."""
         if self.mopo:
             raise NotImplementedError("pre-training with config['mopo'] = 1 is outside the accelerated path "
                                       "(inference / rollouts / checkpoints of such a model are supported)")
         if self._train is None:
             blob = packing.pack_pretrain(self._p, self.obs_dim, self.action_dim, self.device)
             z = lambda: torch.zeros_like(blob)
-            self._train = dict(blob=blob, blob_T=ops.pretrain_transpose(blob, self.obs_dim, self.action_dim), grad=z(),
-                               m=z(), v=z(), t_main=0, t_za={False: 0, True: 0})
+            precision = precision or 0
+            self._train = dict(blob=blob, blob_T=ops.pretrain_transpose(blob, self.obs_dim, self.action_dim, precision=precision),
+                               grad=z(), m=z(), v=z(), t_main=0, t_za={False: 0, True: 0}, prec=precision)
+        elif precision is not None and self._train["prec"] != precision:          # the mode changed under a live training copy: rebuild the planes
+            ops.pretrain_transpose(self._train["blob"], self.obs_dim, self.action_dim, out=self._train["blob_T"], precision=precision)
+            self._train["prec"] = precision
         return self._train
 
     def mark_trained(self):
@@ -180,7 +185,8 @@ class MOBODYModule(object):
         """`_p` changed under a live training blob (load_save): re-pack the weights, keep the Adam state."""
         if self._train is not None:
             self._train["blob"].copy_(packing.pack_pretrain(self._p, self.obs_dim, self.action_dim, self.device))
-            ops.pretrain_transpose(self._train["blob"], self.obs_dim, self.action_dim, out=self._train["blob_T"])
+            ops.pretrain_transpose(self._train["blob"], self.obs_dim, self.action_dim, out=self._train["blob_T"],
+                                   precision=self._train["prec"])
             self._train_ahead = False
 
     # ---- HIP side ----

@@ -74,12 +74,14 @@ __device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, 
 // fp32 layer whose output goes to planes instead of the fp32 image.  Returns the tile's scale exponent (planes hold
 // y * 2^e; 0 outside the f16 mode).  `scr`: 8 floats of LDS for the tile maximum (f16 mode).  Optional copies of the
 // activations: gsave (fp32 rows, this tile's base) and gs (fp16 planes for the weight-gradient GEMM); optional sign words.
-template <int ACT, int MT, int PM, int TB, class Ring, class Between>
+// DS (Swish training forward): dsave also receives d = dy/dz of every element (fp32 rows; mobody_module.py:9-15), with the
+// fp32 training kernel's formulas (sig = 1 / (1 + exp(-z)), y = z sig, d = sig (1 + z (1 - sig)); layers.h wide_layer_swish_d).
+template <int ACT, int MT, int PM, int TB, bool DS = false, class Ring, class Between>
 __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* scr, const float* __restrict__ W,
                                                     const float* __restrict__ b, int Kp, Ring& ring, Between&& between,
                                                     uint32_t* mask = nullptr, bool full = true, int mask_groups = 0,
                                                     int rows_here = 1 << 30, float* gsave = nullptr,
-                                                    const PlaneSave& gs = PlaneSave{nullptr, 0, nullptr}) {
+                                                    const PlaneSave& gs = PlaneSave{nullptr, 0, nullptr}, float* dsave = nullptr) {
   const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
   f32x16 acc[MT][2];
   wide_zero<MT>(acc);
@@ -87,16 +89,35 @@ __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* 
   TR(6);
   between();
   float mx = 0.f;                                  // the activations in place; their largest magnitude for the f16 scale
+  if constexpr (DS) {
+    static_assert(ACT == ACT_SWISH, "derivative saves belong to the Swish nets");
+    f32x16 dv[MT][2];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float y = activate<ACT>(acc[mt][nt][r] + (nt ? bias1 : bias0));
-        acc[mt][nt][r] = y;
-        if constexpr (Split<PM>::F16) mx = fmaxf(mx, fabsf(y));
-      }
+        for (int r = 0; r < 16; ++r) {
+          const float z = acc[mt][nt][r] + (nt ? bias1 : bias0);
+          const float sig = 1.f / (1.f + __expf(-z));
+          const float y = z * sig;
+          acc[mt][nt][r] = y;
+          dv[mt][nt][r] = sig * (1.f + z * (1.f - sig));
+          if constexpr (Split<PM>::F16) mx = fmaxf(mx, fabsf(y));
+        }
+    wide_store_rows<MT>(dv, dsave, full, rows_here);
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float y = activate<ACT>(acc[mt][nt][r] + (nt ? bias1 : bias0));
+          acc[mt][nt][r] = y;
+          if constexpr (Split<PM>::F16) mx = fmaxf(mx, fabsf(y));
+        }
+  }
   // the global plane copy feeds a contraction over ROWS: rows past the end of the batch must be zero there
   // (wave uniform and only on the ragged last tile; their activations are act(bias), harmless for the tile maximum)
   if (gs.base != nullptr && !full) {
@@ -121,11 +142,11 @@ __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* 
 }
 
 // split-precision layer: planes (scaled by 2^e_in in the f16 mode) -> fp32 image (+ optional fp32 copy gsave, sign words)
-template <int ACT, int MT, int PM, int TB, class Between>
+template <int ACT, int MT, int PM, int TB, bool DS = false, class Between>
 __device__ __forceinline__ void bf_layer(float* Xs, const char* Ps, int e_in, const s16x8* __restrict__ Wb,
                                          const float* __restrict__ b, BfRing<PM>& ring, Between&& between,
                                          uint32_t* mask = nullptr, bool full = true, int mask_groups = 0,
-                                         int rows_here = 1 << 30, float* gsave = nullptr) {
+                                         int rows_here = 1 << 30, float* gsave = nullptr, float* dsave = nullptr) {
   const float bias0 = b[64 * wave_col() + (lane_id() & 31)], bias1 = b[64 * wave_col() + 32 + (lane_id() & 31)];
   f32x16 acc[MT][2];
   wide_zero<MT>(acc);
@@ -133,15 +154,32 @@ __device__ __forceinline__ void bf_layer(float* Xs, const char* Ps, int e_in, co
   TR(3);
   between();
   const float inv = Split<PM>::F16 ? exp2i(-(e_in + F16_WSHIFT)) : 1.f;     // exact: both scales are powers of two
+  if constexpr (DS) {
+    f32x16 dv[MT][2];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float bias = nt ? bias1 : bias0;
-        acc[mt][nt][r] = activate<ACT>(Split<PM>::F16 ? fmaf(acc[mt][nt][r], inv, bias) : acc[mt][nt][r] + bias);
-      }
+        for (int r = 0; r < 16; ++r) {
+          const float bias = nt ? bias1 : bias0;
+          const float z = Split<PM>::F16 ? fmaf(acc[mt][nt][r], inv, bias) : acc[mt][nt][r] + bias;
+          const float sig = 1.f / (1.f + __expf(-z));
+          acc[mt][nt][r] = z * sig;
+          dv[mt][nt][r] = sig * (1.f + z * (1.f - sig));
+        }
+    wide_store_rows<MT>(dv, dsave, full, rows_here);
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float bias = nt ? bias1 : bias0;
+          acc[mt][nt][r] = activate<ACT>(Split<PM>::F16 ? fmaf(acc[mt][nt][r], inv, bias) : acc[mt][nt][r] + bias);
+        }
+  }
   lds_barrier();                                   // every wave has read the planes
   wide_foreach<MT>(acc, [&](int row, int col, float y) { Xs[row * LDX + col] = y; });
   if (gsave != nullptr) wide_store_rows<MT>(acc, gsave, full, rows_here);

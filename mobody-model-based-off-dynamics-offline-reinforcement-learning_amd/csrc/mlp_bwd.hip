@@ -341,6 +341,11 @@ static int launch_bwd_masks(const Mlp3BwdArgs& a, int members, bool with_dx, int
 // Swish nets (the ensemble dynamics, pre-training): 32-row tiles only, derivative multipliers in h1 / h2
 static int launch_bwd_swish(const Mlp3BwdArgs& a, int members, bool with_dx, hipStream_t st) {
   const int nt = a.Np1t == 16 ? 1 : a.Np1t == 32 ? 2 : 0;
+  if (a.prec == 4 && a.w2t_planes != nullptr) {     // f16x2: the 256 x 256 GEMM on the split core, dz2 as planes for the weight gradients
+    if (!with_dx) return launch_bwd_t<false, 1, 0, 2, 4>(a, members, st);
+    return nt == 1 ? launch_bwd_t<true, 1, 1, 2, 4>(a, members, st) : nt == 2 ? launch_bwd_t<true, 1, 2, 2, 4>(a, members, st)
+                                                                             : launch_bwd_t<true, 1, 0, 2, 4>(a, members, st);
+  }
   if (!with_dx) return launch_bwd_t<false, 1, 0, 2>(a, members, st);
   return nt == 1 ? launch_bwd_t<true, 1, 1, 2>(a, members, st) : nt == 2 ? launch_bwd_t<true, 1, 2, 2>(a, members, st)
                                                                          : launch_bwd_t<true, 1, 0, 2>(a, members, st);

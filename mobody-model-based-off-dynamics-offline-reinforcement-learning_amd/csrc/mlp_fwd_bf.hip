@@ -19,7 +19,8 @@
 #endif
 namespace mobody {
 
-template <int ACT, int PM, int RG, int NT>
+// DS: training forward of a Swish net -- save_d1 / save_d2 receive the derivatives next to h1 (planes or rows) / h2
+template <int ACT, int PM, int RG, int NT, bool DS = false>
 __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, float* Xs) {
   constexpr int MT = 1, TB = 32 * RG;
   char* Ps = reinterpret_cast<char*>(Xs);
@@ -53,6 +54,8 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
   }
   float* h1 = a.save_h1 ? a.save_h1 + ((long long)m * a.rows + row0) * HID : nullptr;
   float* h2 = a.save_h2 ? a.save_h2 + ((long long)m * a.rows + row0) * HID : nullptr;
+  float* d1 = DS ? a.save_d1 + ((long long)m * a.rows + row0) * HID : nullptr;
+  float* d2 = DS ? a.save_d2 + ((long long)m * a.rows + row0) * HID : nullptr;
   const long long mtile = ((long long)m * cdiv(a.rows, 32) + row0 / 32) * HID;
   uint32_t* mask1 = a.mask1 ? a.mask1 + mtile : nullptr;
   uint32_t* mask2 = a.mask2 ? a.mask2 + mtile : nullptr;
@@ -64,8 +67,8 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
     gs.plane_stride = a.h1p_plane;
     gs.e_out = a.save_e1 + (long long)m * cdiv(a.rows, 32) + row0 / 32;
   }
-  const int e1 = wide_layer_to_planes<ACT, MT, PM, TB>(Xs, Ps, scr, w1, a.b1 + m * a.sb1, a.Kp1, ring,
-                                                       [&] { bf_prefetch<PM>(w2b, bring); }, mask1, full, mg, rows_here, h1, gs);
+  const int e1 = wide_layer_to_planes<ACT, MT, PM, TB, DS>(Xs, Ps, scr, w1, a.b1 + m * a.sb1, a.Kp1, ring,
+                                                           [&] { bf_prefetch<PM>(w2b, bring); }, mask1, full, mg, rows_here, h1, gs, d1);
   TR(2);
   float* out = a.out + m * a.out_mstride + row0 * a.out_ld;
   auto emit = [&](int row, int col, float v, float bias) {
@@ -80,41 +83,41 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
     NarrowRegs<NT> br;
     const int mycol = threadIdx.x % (16 * NT);
     float bias;
-    bf_layer<ACT, MT, PM, TB>(Xs, Ps, e1, w2b, a.b2 + m * a.sb2, bring, [&] {
+    bf_layer<ACT, MT, PM, TB, DS>(Xs, Ps, e1, w2b, a.b2 + m * a.sb2, bring, [&] {
       narrow_prefetch<NT>(w3, 16 * NT, br);
       bias = b3[mycol < a.nout ? mycol : 0];
-    }, mask2, full, mg, rows_here, h2);
+    }, mask2, full, mg, rows_here, h2, d2);
     TR(4);
     narrow_run<TB / 16, NT>(Xs, br, [&](int row, int col, float v) { emit(row, col, v, bias); });
   } else {
-    bf_layer<ACT, MT, PM, TB>(Xs, Ps, e1, w2b, a.b2 + m * a.sb2, bring, [] {}, mask2, full, mg, rows_here, h2);
+    bf_layer<ACT, MT, PM, TB, DS>(Xs, Ps, e1, w2b, a.b2 + m * a.sb2, bring, [] {}, mask2, full, mg, rows_here, h2, d2);
     narrow_layer(Xs, w3, HID, a.Np3, [&](int row, int col, float v) { emit(row, col, v, b3[col < a.nout ? col : 0]); }, TB);
   }
   TR(5);
 }
 
 // one or two independent networks per launch (blockIdx.y < members_a -> net a), as k_mlp3_fwd2
-template <int ACT, int PM, int RG, int NT>
-__global__ __launch_bounds__(NTHREADS * RG, (PM == 4 && RG == 1) ? FWD_F16_WAVES : 2) void k_mlp3_fwd_bf(Mlp3FwdArgs a, Mlp3FwdArgs b, int members_a) {
+template <int ACT, int PM, int RG, int NT, bool DS = false>
+__global__ __launch_bounds__(NTHREADS * RG, (PM == 4 && RG == 1 && !DS) ? FWD_F16_WAVES : 2) void k_mlp3_fwd_bf(Mlp3FwdArgs a, Mlp3FwdArgs b, int members_a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   const bool second = (int)blockIdx.y >= members_a;
   const Mlp3FwdArgs s = second ? b : a;
   if ((long long)blockIdx.x * (32 * RG) >= s.rows) return;
-  mlp3_fwd_bf_tile<ACT, PM, RG, NT>(s, second ? (int)blockIdx.y - members_a : (int)blockIdx.y, Xs);
+  mlp3_fwd_bf_tile<ACT, PM, RG, NT, DS>(s, second ? (int)blockIdx.y - members_a : (int)blockIdx.y, Xs);
 }
 
-template <int ACT, int PM, int RG, int NT>
+template <int ACT, int PM, int RG, int NT, bool DS = false>
 static int launch_bf_t(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, hipStream_t st) {
   constexpr size_t lds = split_lds_bytes<PM, 32 * RG>();
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_mlp3_fwd_bf<ACT, PM, RG, NT>, 160 * 1024);
+    int rc = allow_big_lds(k_mlp3_fwd_bf<ACT, PM, RG, NT, DS>, 160 * 1024);
     if (rc) return rc;
     once = true;
   }
   const long long rows = a.rows > b.rows ? a.rows : b.rows;
   ProfScope prof(PROF_MLP_FWD, st);
-  hipLaunchKernelGGL((k_mlp3_fwd_bf<ACT, PM, RG, NT>), dim3((unsigned)cdiv(rows, 32 * RG), (unsigned)(members_a + members_b)),
+  hipLaunchKernelGGL((k_mlp3_fwd_bf<ACT, PM, RG, NT, DS>), dim3((unsigned)cdiv(rows, 32 * RG), (unsigned)(members_a + members_b)),
                      dim3(NTHREADS * RG), lds, st, a, b, members_a);
   MB_LAUNCH_OK("k_mlp3_fwd_bf");
   return 0;
@@ -136,6 +139,13 @@ int launch_mlp3_fwd_bf(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b
   Mlp3FwdArgs x = a, y = b; int mx = members_a, my = members_b;
   if (x.rows <= 0) { x = b; mx = members_b; y.rows = 0; my = 0; }
   if (y.rows <= 0) my = 0;
+  if (x.save_d1 != nullptr || x.save_d2 != nullptr) {  // training forward of a Swish net (dynamics pre-training): f16x2, one net
+    if (act != ACT_SWISH || prec != 4 || my != 0 || !x.save_d1 || !x.save_d2)
+      return fail(MOBODY_E_ARG, "launch_mlp3_fwd_bf: derivative saves need one Swish net in the f16x2 mode");
+    const int np3 = x.Np3;
+    return np3 == 16 ? launch_bf_t<ACT_SWISH, 4, 1, 1, true>(x, mx, y, 0, st) : np3 == 32 ? launch_bf_t<ACT_SWISH, 4, 1, 2, true>(x, mx, y, 0, st)
+                                                                              : launch_bf_t<ACT_SWISH, 4, 1, 0, true>(x, mx, y, 0, st);
+  }
 #define BF_CASE(ACT, PM) (rg == 1 ? launch_bf_nt<ACT, PM, 1>(x, mx, y, my, st) : launch_bf_nt<ACT, PM, 2>(x, mx, y, my, st))
   if (act == ACT_SWISH) return prec == 1 ? BF_CASE(ACT_SWISH, 1) : prec == 2 ? BF_CASE(ACT_SWISH, 2) : prec == 3 ? BF_CASE(ACT_SWISH, 3) : BF_CASE(ACT_SWISH, 4);
   return prec == 1 ? BF_CASE(ACT_RELU, 1) : prec == 2 ? BF_CASE(ACT_RELU, 2) : prec == 3 ? BF_CASE(ACT_RELU, 3) : BF_CASE(ACT_RELU, 4);

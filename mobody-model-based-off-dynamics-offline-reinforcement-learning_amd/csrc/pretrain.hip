@@ -138,6 +138,7 @@ struct PreRow {
   float* dz3enc;             // [E][2b][32]
   float* zap;                // [chunks][E][za_mf] action-encoder gradient partials
   float* lossp;              // loss partial sums (see PreLossOff)
+  float* fnz;                // [E][b][S] the fake-next-state noise draws of this step (k_pre_trans_loss -> k_pre_fake_bwd)
 };
 // lossp regions (floats): latent chunks [E*nch][2] (latent, kl) | row-tile chunks [nrt][2] (recon, trans) | reward [nrw]
 struct PreLossOff { long long lat, rt, rw; int n_lat, n_rt, n_rw; };
@@ -257,42 +258,49 @@ __global__ __launch_bounds__(256) void k_pre_latent_fwd(PreRow a, PreLossOff lo,
   }
 }
 
-// one thread per (row, state dim): reconstruction / transition residuals -> decoder output gradients (quarters 0..2),
-// the sampled fake next state and the reward head's input rows.
+// one thread per (member, row, state dim): reconstruction / transition residuals -> decoder output gradients (quarters 0..2),
+// the sampled fake next state (its noise draw is kept in fnz for k_pre_fake_bwd) and the reward head's input rows.  Every load
+// of a thread is independent of its stores (one round trip), and a thread draws ONE normal: with a thread per (row, dim)
+// looping over the members the seven Philox + Box-Muller evaluations and seven dependent load / store rounds made this
+// 17-workgroup kernel 15 us of the step's critical path.
 __global__ __launch_bounds__(256) void k_pre_trans_loss(PreRow a, PreLossOff lo) {
   __shared__ float sm[8];
   const int S = a.S, A = a.A, W = 2 * S + A, Np3 = a.Np3tr;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool ok = i < a.b * S;
-  const long long row = ok ? i / S : 0;
-  const int d = ok ? (int)(i - row * S) : 0;
   const long long b = a.b;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ok = i < NENS * b * S;
+  const long long ic = ok ? i : 0;
+  const int e = (int)(ic / (b * S));
+  const long long row = (ic - (long long)e * b * S) / S;
+  const int d = (int)(ic - ((long long)e * b + row) * S);
   const float c_rec = a.ce * 100.f * 2.f * a.inv_bg / (float)S, c_tr = 2.f * a.inv_bg / (float)S;
-  float rec = 0.f, tr = 0.f;
   float m6[NENS], avg = 0.f;
 #pragma unroll
-  for (int e = 0; e < NENS; ++e) { m6[e] = a.tr_out[((long long)e * 4 * b + 3 * b + row) * S + d]; avg += m6[e]; }
+  for (int k = 0; k < NENS; ++k) { m6[k] = a.tr_out[((long long)k * 4 * b + 3 * b + row) * S + d]; avg += m6[k]; }
+  const float* to = a.tr_out + (long long)e * 4 * b * S;
+  const float s = a.xenc[((long long)e * 2 * b + row) * S + d], s2 = a.xenc[((long long)e * 2 * b + b + row) * S + d];
+  const float o0 = to[row * S + d], o1 = to[(b + row) * S + d], o2 = to[(2 * b + row) * S + d];
+  const float aj0 = a.act[((long long)e * b + row) * A + (d < A ? d : 0)];
+  const float nz = pre_noise(a, 6, e, row, d, S);
   avg *= (1.f / NENS);
-  float var = 0.f;
+  float var = 0.f, mine = 0.f;
 #pragma unroll
-  for (int e = 0; e < NENS; ++e) { const float t = m6[e] - avg; var += t * t; }
+  for (int k = 0; k < NENS; ++k) { const float t = m6[k] - avg; var += t * t; mine = k == e ? m6[k] : mine; }
   const float sd = sqrtf(var * (1.f / (NENS - 1)));                         // torch.std over the ensemble axis, unbiased (:353)
-#pragma unroll
-  for (int e = 0; e < NENS; ++e) {
-    const float* to = a.tr_out + (long long)e * 4 * b * S;
-    const float s = a.xenc[((long long)e * 2 * b + row) * S + d], s2 = a.xenc[((long long)e * 2 * b + b + row) * S + d];
-    const float r0 = to[row * S + d] - s, r1 = to[(b + row) * S + d] - s2, t5 = to[(2 * b + row) * S + d] - s2;
-    if (ok) {
-      float* g = a.dz3tr + (long long)e * 4 * b * Np3;
-      g[row * Np3 + d] = c_rec * r0; g[(b + row) * Np3 + d] = c_rec * r1; g[(2 * b + row) * Np3 + d] = c_tr * t5;
-      for (int c = S + d; c < Np3; c += S) { g[row * Np3 + c] = 0.f; g[(b + row) * Np3 + c] = 0.f; g[(2 * b + row) * Np3 + c] = 0.f; }
-      rec += r0 * r0 + r1 * r1; tr += t5 * t5;
-      float* x = a.xrw + (long long)e * 2 * b * W;
-      x[row * W + d] = s; x[(b + row) * W + d] = s;
-      x[row * W + S + A + d] = m6[e] + pre_noise(a, 6, e, row, d, S) * sd;       // fake next state (:353)
-      x[(b + row) * W + S + A + d] = s2;
-      for (int j = d; j < A; j += S) { const float aj = a.act[((long long)e * b + row) * A + j]; x[row * W + S + j] = aj; x[(b + row) * W + S + j] = aj; }
-    }
+  float rec = 0.f, tr = 0.f;
+  if (ok) {
+    const float r0 = o0 - s, r1 = o1 - s2, t5 = o2 - s2;
+    float* g = a.dz3tr + (long long)e * 4 * b * Np3;
+    g[row * Np3 + d] = c_rec * r0; g[(b + row) * Np3 + d] = c_rec * r1; g[(2 * b + row) * Np3 + d] = c_tr * t5;
+    for (int c = S + d; c < Np3; c += S) { g[row * Np3 + c] = 0.f; g[(b + row) * Np3 + c] = 0.f; g[(2 * b + row) * Np3 + c] = 0.f; }
+    rec = r0 * r0 + r1 * r1; tr = t5 * t5;
+    float* x = a.xrw + (long long)e * 2 * b * W;
+    x[row * W + d] = s; x[(b + row) * W + d] = s;
+    x[row * W + S + A + d] = mine + nz * sd;                                // fake next state (:353)
+    x[(b + row) * W + S + A + d] = s2;
+    a.fnz[ic] = nz;
+    if (d < A) { x[row * W + S + d] = aj0; x[(b + row) * W + S + d] = aj0; }
+    for (int j = d + S; j < A; j += S) { const float aj = a.act[((long long)e * b + row) * A + j]; x[row * W + S + j] = aj; x[(b + row) * W + S + j] = aj; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { rec += __shfl_xor(rec, o); tr += __shfl_xor(tr, o); }
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(256) void k_pre_fake_bwd(PreRow a) {
     m6[e] = a.tr_out[((long long)e * 4 * b + 3 * b + row) * S + d];
     g[e] = a.dfake[((long long)e * 2 * b + row) * S + d];
     avg += m6[e];
-    G += g[e] * pre_noise(a, 6, e, row, d, S);
+    G += g[e] * a.fnz[((long long)e * b + row) * S + d];      // the draw k_pre_trans_loss made (and kept) for this element
   }
   avg *= (1.f / NENS);
   float var = 0.f;
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(256) void k_pre_za_reduce(const float* zap, int nch
 // out[5] = (loss, transition_loss, encoder_loss, recon_loss, kl_loss) as learn() reports them (:630-650); local shares
 // of the global means when data parallel.
 __global__ __launch_bounds__(256) void k_pre_loss_final(const float* lossp, PreLossOff lo, float inv_bg, int S, float ce,
-                                                        float cr, float* out) {
+                                                        float cr, float* out, float* acc) {
   __shared__ float sm[5][4];
   float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};                // latent, kl, recon, trans, reward
   for (int k = threadIdx.x; k < lo.n_lat; k += 256) { v[0] += lossp[lo.lat + 2 * k]; v[1] += lossp[lo.lat + 2 * k + 1]; }
@@ -491,6 +499,7 @@ __global__ __launch_bounds__(256) void k_pre_loss_final(const float* lossp, PreL
     const float recon = t[2] * inv_bg / S, trans = t[3] * inv_bg / S, rl = cr * t[4] * inv_bg;
     const float enc = 100.f * recon + kl + lat;
     out[0] = trans + ce * enc + rl; out[1] = trans; out[2] = enc; out[3] = recon; out[4] = kl;
+    if (acc != nullptr) { acc[0] += out[0]; acc[1] += trans; acc[2] += enc; acc[3] += recon; acc[4] += kl; }   // learn()'s running sums (:630-650)
   }
 }
 
@@ -549,7 +558,11 @@ struct PreWs {
   float *enc_out, *sx_enc, *h1e, *h2e, *d1e, *d2e;
   float *zt, *h1t, *h2t, *d1t, *d2t, *tr_out;
   float *xrw, *sx_rw, *h1r, *h2r, *d1r, *d2r, *rw_out;
-  float *dz3rw, *dz3tr, *dz3enc, *dz2, *dz1, *dfake, *dzt, *dbp, *slabs, *zap, *lossp;
+  float *dz3rw, *dz3tr, *dz3enc, *dfake, *dzt, *zap, *lossp, *fnz;
+  // backward operands of the three nets (0 reward head, 1 decoder, 2 state encoder): one set EACH, because the weight-gradient
+  // GEMM + reduction of nets 0 and 1 run on the side stream while the main stream's backward chain moves on to the next net
+  float *dz2[3], *dz1[3], *dbp[3], *slabs[3];
+  int *eh1e, *eh1t, *eh1r, *edz2[3];   // f16x2: scale exponents of the 32-row tiles of the h1 / dz2 planes (h1*, dz2 then hold planes)
   PreLossOff lo;
   int nch, nsplit2, nsplit4, ntiles2, ntiles4;
   long long total;
@@ -557,39 +570,52 @@ struct PreWs {
 
 static int pre_carve(const MobodyPretrainLayout& L, long long b, float* base, PreWs& w) {
   const long long E = NENS, R2 = 2 * b, R4 = 4 * b;
+  const long long R2p = (R2 + 31) & ~31LL, R4p = (R4 + 31) & ~31LL;     // the fp16 planes of h1 / dz2 are padded to whole 32-row tiles
   const int S = L.S, A = L.A;
   long long off = 0;
   auto take = [&](long long n) { float* p = base ? base + off : nullptr; off += (n + 3) & ~3LL; return p; };
   w.enc_out = take(E * R2 * 32); w.sx_enc = take(E * R2 * L.enc.Kp1);
-  w.h1e = take(E * R2 * HID); w.h2e = take(E * R2 * HID); w.d1e = take(E * R2 * HID); w.d2e = take(E * R2 * HID);
+  w.h1e = take(E * R2p * HID); w.h2e = take(E * R2 * HID); w.d1e = take(E * R2 * HID); w.d2e = take(E * R2 * HID);
   w.zt = take(E * R4 * LATENT);
-  w.h1t = take(E * R4 * HID); w.h2t = take(E * R4 * HID); w.d1t = take(E * R4 * HID); w.d2t = take(E * R4 * HID);
+  w.h1t = take(E * R4p * HID); w.h2t = take(E * R4 * HID); w.d1t = take(E * R4 * HID); w.d2t = take(E * R4 * HID);
   w.tr_out = take(E * R4 * S);
   w.xrw = take(E * R2 * (2 * S + A)); w.sx_rw = take(E * R2 * L.rw.Kp1);
-  w.h1r = take(E * R2 * HID); w.h2r = take(E * R2 * HID); w.d1r = take(E * R2 * HID); w.d2r = take(E * R2 * HID);
+  w.h1r = take(E * R2p * HID); w.h2r = take(E * R2 * HID); w.d1r = take(E * R2 * HID); w.d2r = take(E * R2 * HID);
   w.rw_out = take(E * R2 * 2);
   w.dz3rw = take(E * R2 * 16); w.dz3tr = take(E * R4 * L.tr.Np3); w.dz3enc = take(E * R2 * 32);
-  w.dz2 = take(E * R4 * HID); w.dz1 = take(E * R4 * HID);
-  w.dfake = take(E * R2 * S); w.dzt = take(E * R4 * LATENT);
+  const long long rows_of[3] = {R2, R4, R2}, rowsp_of[3] = {R2p, R4p, R2p};
+  for (int k = 0; k < 3; ++k) { w.dz2[k] = take(E * rowsp_of[k] * HID); w.dz1[k] = take(E * rows_of[k] * HID); }
+  w.dfake = take(E * R2 * S); w.dzt = take(E * R4 * LATENT); w.fnz = take(E * b * S);
   w.ntiles2 = (int)cdiv(R2, 32); w.ntiles4 = (int)cdiv(R4, 32);
+  w.eh1e = reinterpret_cast<int*>(take(E * w.ntiles2)); w.eh1r = reinterpret_cast<int*>(take(E * w.ntiles2));
+  w.eh1t = reinterpret_cast<int*>(take(E * w.ntiles4));
+  for (int k = 0; k < 3; ++k) w.edz2[k] = reinterpret_cast<int*>(take(E * (k == 1 ? w.ntiles4 : w.ntiles2)));
   const long long per = 2 * HID + (L.tr.Np3 > 32 ? L.tr.Np3 : 32);
-  w.dbp = take((long long)w.ntiles4 * E * per);
+  for (int k = 0; k < 3; ++k) w.dbp[k] = take((long long)(k == 1 ? w.ntiles4 : w.ntiles2) * E * per);
   w.nsplit2 = wgrad_nsplit(R2, NENS); w.nsplit4 = wgrad_nsplit(R4, NENS);
-  long long tf = L.enc.total_floats > L.tr.total_floats ? L.enc.total_floats : L.tr.total_floats;
-  if (L.rw.total_floats > tf) tf = L.rw.total_floats;
-  w.slabs = take(((tf + 3) & ~3LL) * (w.nsplit4 > w.nsplit2 ? w.nsplit4 : w.nsplit2));
+  w.slabs[0] = take(((L.rw.total_floats + 3) & ~3LL) * w.nsplit2);
+  w.slabs[1] = take(((L.tr.total_floats + 3) & ~3LL) * w.nsplit4);
+  w.slabs[2] = take(((L.enc.total_floats + 3) & ~3LL) * w.nsplit2);
   w.nch = (int)cdiv(b, LROWS);
   w.zap = take((long long)w.nch * E * L.za_member_floats);
-  w.lo.n_lat = (int)(E * w.nch); w.lo.n_rt = (int)cdiv(b * S, 256); w.lo.n_rw = (int)cdiv(E * R2, 256);
+  w.lo.n_lat = (int)(E * w.nch); w.lo.n_rt = (int)cdiv(E * b * S, 256); w.lo.n_rw = (int)cdiv(E * R2, 256);
   w.lo.lat = 0; w.lo.rt = 2LL * w.lo.n_lat; w.lo.rw = w.lo.rt + 2LL * w.lo.n_rt;
   w.lossp = take(w.lo.rw + w.lo.n_rw);
   w.total = off;
   return 0;
 }
 
+// blob_T / e1 (f16x2): W2's fp16 planes from the T blob; h1 receives planes + tile exponents instead of fp32 rows
 static Mlp3FwdArgs pre_fwd_args(const float* blob, const MobodyMlpLayout& L, const float* src, int n, long long rows, float* out,
-                                float* sx, float* h1, float* h2, float* d1, float* d2) {
+                                float* sx, float* h1, float* h2, float* d1, float* d2, const float* blob_T = nullptr,
+                                int* e1 = nullptr) {
   Mlp3FwdArgs a{};
+  if (e1 != nullptr) {
+    const long long r32 = (rows + 31) & ~31LL;
+    a.save_h1p = reinterpret_cast<unsigned short*>(h1); a.h1p_plane = r32 * HID; a.h1p_ms = 2 * r32 * HID; a.save_e1 = e1;
+    a.w2_planes = reinterpret_cast<const unsigned short*>(blob_T + L.w2p); a.planes_ms = 2 * L.t_member_floats;
+    h1 = nullptr;
+  }
   a.src[0] = src; a.ld[0] = n; a.n[0] = n; a.src_ms[0] = rows * n;
   a.w1 = blob + L.w1; a.b1 = blob + L.b1; a.w2 = blob + L.w2; a.b2 = blob + L.b2; a.w3 = blob + L.w3; a.b3 = blob + L.b3;
   a.sw1 = a.sb1 = a.sw2 = a.sb2 = a.sw3 = a.sb3 = L.member_floats;
@@ -600,8 +626,14 @@ static Mlp3FwdArgs pre_fwd_args(const float* blob, const MobodyMlpLayout& L, con
 }
 
 static Mlp3BwdArgs pre_bwd_args(const MobodyMlpLayout& L, const float* blob_T, const float* dz3, const float* d1, const float* d2,
-                                long long rows, float* dz2, float* dz1, float* dbp) {
+                                long long rows, float* dz2, float* dz1, float* dbp, int* e2 = nullptr) {
   Mlp3BwdArgs b{};
+  if (e2 != nullptr) {                              // f16x2: dz2 leaves as planes + tile exponents, W2^T's planes from the T blob
+    const long long r32 = (rows + 31) & ~31LL;
+    b.dz2p = reinterpret_cast<unsigned short*>(dz2); b.dz2p_plane = r32 * HID; b.dz2p_ms = 2 * r32 * HID; b.e2_out = e2;
+    b.prec = 4; b.w2t_planes = reinterpret_cast<const unsigned short*>(blob_T + L.w2tp); b.planes_ms = 2 * L.t_member_floats;
+    dz2 = nullptr;
+  }
   b.dz3 = dz3; b.h1 = d1; b.h2 = d2; b.swish = 1; b.wt = blob_T; b.t_mstride = L.t_member_floats;
   b.w3t = L.w3t; b.w2t = L.w2t; b.w1t = L.w1t; b.Np3 = L.Np3; b.Np1t = L.Np1t; b.rows = rows;
   b.dz2 = dz2; b.dz1 = dz1; b.dbp = dbp;
@@ -642,14 +674,21 @@ extern "C" int mobody_pretrain_layout(int S, int A, MobodyPretrainLayout* out) {
   return 0;
 }
 
-extern "C" int mobody_pretrain_transpose(int S, int A, const float* blob, float* blob_T, void* stream) {
+static int pre_check_prec(int precision, const char* who) {
+  MB_REQUIRE(precision == 0 || precision == 4, "%s: pre-training runs in precision 0 (f32) or 4 (f16x2)", who);
+  return 0;
+}
+
+extern "C" int mobody_pretrain_transpose(int S, int A, const float* blob, float* blob_T, int precision, void* stream) {
   MobodyPretrainLayout L;
   int rc = mobody_pretrain_layout(S, A, &L);
   if (rc) return rc;
   MB_REQUIRE(blob && blob_T, "mobody_pretrain_transpose: null pointer");
-  rc = mobody_mlp_transpose(S, 2 * LATENT, NENS, blob + L.off_enc, blob_T + L.t_off_enc, 0, stream);
-  if (!rc) rc = mobody_mlp_transpose(LATENT, S, NENS, blob + L.off_tr, blob_T + L.t_off_tr, 0, stream);
-  if (!rc) rc = mobody_mlp_transpose(2 * S + A, 2, NENS, blob + L.off_rw, blob_T + L.t_off_rw, 0, stream);
+  rc = pre_check_prec(precision, "mobody_pretrain_transpose");
+  if (rc) return rc;
+  rc = mobody_mlp_transpose(S, 2 * LATENT, NENS, blob + L.off_enc, blob_T + L.t_off_enc, precision, stream);
+  if (!rc) rc = mobody_mlp_transpose(LATENT, S, NENS, blob + L.off_tr, blob_T + L.t_off_tr, precision, stream);
+  if (!rc) rc = mobody_mlp_transpose(2 * S + A, 2, NENS, blob + L.off_rw, blob_T + L.t_off_rw, precision, stream);
   return rc;
 }
 
@@ -678,7 +717,7 @@ extern "C" int mobody_pretrain_gather(const float* state, const float* action, c
 namespace mobody {
 // torch.optim.Adam scalar bookkeeping in double (same forms as train.hip's adam_target); t_dev: device step count
 static AdamTarget pre_adam_target(float* p, float* pT, float* m, float* v, int64_t t, const int64_t* t_dev, float lr,
-                                  float grad_scale) {
+                                  float grad_scale, int precision = 0) {
   const double tt = t_dev ? 1.0 : (double)t;
   const double bc1 = 1.0 - pow(0.9, tt), bc2 = 1.0 - pow(0.999, tt);
   AdamTarget a{};
@@ -687,9 +726,37 @@ static AdamTarget pre_adam_target(float* p, float* pT, float* m, float* v, int64
   a.c.step_size = (float)((double)lr / bc1); a.c.bc2_sqrt = (float)sqrt(bc2); a.c.eps = 1e-8f;
   a.c.tau = -1.f; a.c.one_minus_tau = 0.f; a.c.gscale = grad_scale;
   a.t_dev = (const long long*)t_dev; a.lr = lr; a.on = 1;
-  a.precision = -1;                               // pre-training is exact fp32: the W2 planes of its T blob are never read
+  a.precision = precision == 4 ? 4 : -1;          // exact fp32 never reads the W2 planes of its T blob; f16x2 keeps them current
   return a;
 }
+// Side stream of the step.  After a net's backward kernel its weight-gradient GEMM and the gradient reduction (with the fused
+// Adam step) feed nothing later in the step, while the main chain -- 13 dependent launches of 17 .. 224 workgroups that leave
+// most of the 256 CUs idle -- still has the next net's backward to run: the reward head's and the decoder's (~26 us each) go to
+// a library-owned second stream between two events and rejoin before the loss is finalised.  Under stream capture the event
+// pair pulls the side stream into the caller's graph as a parallel branch.  PRE_SIDE_STREAM=0 builds the single-stream order.
+#ifndef PRE_SIDE_STREAM
+#define PRE_SIDE_STREAM 1
+#endif
+struct PreSide { hipStream_t s; hipEvent_t fork[3], join; };
+static int pre_side(PreSide** out) {
+  static PreSide side[16];
+  static bool have[16] = {false};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return fail(MOBODY_E_LAUNCH, "pre-training: hipGetDevice failed");
+  if (!have[dev]) {
+    PreSide& p = side[dev];
+    if (hipStreamCreateWithFlags(&p.s, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&p.fork[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p.fork[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p.fork[2], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p.join, hipEventDisableTiming) != hipSuccess)
+      return fail(MOBODY_E_LAUNCH, "pre-training: could not create the side stream");
+    have[dev] = true;
+  }
+  *out = &side[dev];
+  return 0;
+}
+
 struct PreOpt {             // fused optimizer step (single GPU): Adam state and step counts; on = 0 -> gradients only
   int on;
   float *blob, *blob_T, *m, *v;
@@ -702,16 +769,19 @@ struct PreOpt {             // fused optimizer step (single GPU): Adam state and
 static int pretrain_impl(int S, int A, int64_t b, int64_t b_global, int use_trg, float encoder_loss_coef,
                          const float* blob, const float* blob_T, const float* xenc, const float* act,
                          const float* rew, const float* noise6, const float* noise7, uint32_t seed, uint32_t call,
-                         const int64_t* call_dev, float* grad, const PreOpt& opt, float* loss_out, float* workspace,
-                         void* stream) {
+                         const int64_t* call_dev, float* grad, const PreOpt& opt, float* loss_out, float* loss_acc,
+                         float* workspace, int precision, void* stream) {
   MobodyPretrainLayout L;
   int rc = mobody_pretrain_layout(S, A, &L);
   if (rc) return rc;
+  rc = pre_check_prec(precision, "mobody_pretrain");
+  if (rc) return rc;
+  const bool f16 = precision == 4;
   MB_REQUIRE(b >= 1 && b_global >= b, "mobody_pretrain: need 1 <= b <= b_global");
   MB_REQUIRE(blob && blob_T && xenc && act && rew && (grad || opt.on) && loss_out && workspace, "mobody_pretrain: null pointer");
   auto region_adam = [&](int64_t off, int64_t toff) {
     if (!opt.on) return AdamTarget{};
-    return pre_adam_target(opt.blob + off, opt.blob_T + toff, opt.m + off, opt.v + off, opt.t_main, opt.t_dev, opt.lr, 1.f);
+    return pre_adam_target(opt.blob + off, opt.blob_T + toff, opt.m + off, opt.v + off, opt.t_main, opt.t_dev, opt.lr, 1.f, precision);
   };
   auto gptr = [&](int64_t off) { return grad ? grad + off : nullptr; };
   PreWs w;
@@ -734,44 +804,65 @@ static int pretrain_impl(int S, int A, int64_t b, int64_t b_global, int use_trg,
   r.za = blob + (use_trg ? L.off_za_trg : L.off_za_src);
   r.za_mf = L.za_member_floats; r.za_w1 = L.za_w1; r.za_b1 = L.za_b1; r.za_w2 = L.za_w2; r.za_b2 = L.za_b2;
   r.enc_out = w.enc_out; r.zt = w.zt; r.tr_out = w.tr_out; r.dz3tr = w.dz3tr; r.xrw = w.xrw; r.rw_out = w.rw_out;
-  r.dz3rw = w.dz3rw; r.dfake = w.dfake; r.dzt = w.dzt; r.dz3enc = w.dz3enc; r.zap = w.zap; r.lossp = w.lossp;
+  r.dz3rw = w.dz3rw; r.dfake = w.dfake; r.dzt = w.dzt; r.dz3enc = w.dz3enc; r.zap = w.zap; r.lossp = w.lossp; r.fnz = w.fnz;
   const float *Penc = blob + L.off_enc, *Ptr = blob + L.off_tr, *Prw = blob + L.off_rw;
   const float *Tenc = blob_T + L.t_off_enc, *Ttr = blob_T + L.t_off_tr, *Trw = blob_T + L.t_off_rw;
 
+  // f16x2: the 256 x 256 layers of the three nets on the split core (mlp_fwd_bf.hip with derivative saves)
+  auto forward = [&](const Mlp3FwdArgs& fa) {
+    return f16 ? launch_mlp3_fwd_bf(fa, NENS, Mlp3FwdArgs{}, 0, ACT_SWISH, 4, st) : launch_fwd_train(fa, NENS, st);
+  };
   // ---- forward ----
-  rc = launch_fwd_train(pre_fwd_args(Penc, L.enc, xenc, S, R2, w.enc_out, w.sx_enc, w.h1e, w.h2e, w.d1e, w.d2e), NENS, st);
+  rc = forward(pre_fwd_args(Penc, L.enc, xenc, S, R2, w.enc_out, w.sx_enc, w.h1e, w.h2e, w.d1e, w.d2e, Tenc, f16 ? w.eh1e : nullptr));
   if (rc) return rc;
   const LatentLds ll = latent_lds(L.za_member_floats, A);
   hipLaunchKernelGGL(k_pre_latent_fwd, dim3((unsigned)w.nch, NENS), dim3(256), sizeof(float) * (size_t)ll.total, st, r, w.lo, ll);
   MB_LAUNCH_OK("k_pre_latent_fwd");
-  rc = launch_fwd_train(pre_fwd_args(Ptr, L.tr, w.zt, LATENT, R4, w.tr_out, nullptr, w.h1t, w.h2t, w.d1t, w.d2t), NENS, st);
+  rc = forward(pre_fwd_args(Ptr, L.tr, w.zt, LATENT, R4, w.tr_out, nullptr, w.h1t, w.h2t, w.d1t, w.d2t, Ttr, f16 ? w.eh1t : nullptr));
   if (rc) return rc;
   hipLaunchKernelGGL(k_pre_trans_loss, dim3((unsigned)w.lo.n_rt), dim3(256), 0, st, r, w.lo);
   MB_LAUNCH_OK("k_pre_trans_loss");
-  rc = launch_fwd_train(pre_fwd_args(Prw, L.rw, w.xrw, 2 * S + A, R2, w.rw_out, w.sx_rw, w.h1r, w.h2r, w.d1r, w.d2r), NENS, st);
+  rc = forward(pre_fwd_args(Prw, L.rw, w.xrw, 2 * S + A, R2, w.rw_out, w.sx_rw, w.h1r, w.h2r, w.d1r, w.d2r, Trw, f16 ? w.eh1r : nullptr));
   if (rc) return rc;
+  PreSide* side = nullptr;
+  hipStream_t st2 = st;                              // where the off-chain weight-gradient work goes
+  if (PRE_SIDE_STREAM) {
+    rc = pre_side(&side);
+    if (rc) return rc;
+    st2 = side->s;
+  }
+  auto fork = [&](int k) {                           // side stream: wait for everything enqueued on the main stream so far
+    if (!PRE_SIDE_STREAM) return 0;
+    if (hipEventRecord(side->fork[k], st) != hipSuccess || hipStreamWaitEvent(st2, side->fork[k], 0) != hipSuccess)
+      return fail(MOBODY_E_LAUNCH, "pre-training: fork onto the side stream failed");
+    return 0;
+  };
   // ---- backward: reward head (its input gradient feeds the decoder's fourth quarter) ----
   hipLaunchKernelGGL(k_pre_reward_seed, dim3((unsigned)w.lo.n_rw), dim3(256), 0, st, r, w.lo);
   MB_LAUNCH_OK("k_pre_reward_seed");
   {
-    Mlp3BwdArgs bw = pre_bwd_args(L.rw, Trw, w.dz3rw, w.d1r, w.d2r, R2, w.dz2, w.dz1, w.dbp);
+    Mlp3BwdArgs bw = pre_bwd_args(L.rw, Trw, w.dz3rw, w.d1r, w.d2r, R2, w.dz2[0], w.dz1[0], w.dbp[0], f16 ? w.edz2[0] : nullptr);
     bw.dx = w.dfake; bw.dx_c0 = S + A; bw.dx_n = S;
     rc = launch_mlp3_bwd(bw, NENS, true, 32, st);
+    if (!rc) rc = fork(0);
     if (rc) return rc;
-    rc = mlp3_weight_grads(L.rw, w.sx_rw, R2 * L.rw.Kp1, w.h1r, w.h2r, w.dz3rw, w.dz2, w.dz1, R2, w.nsplit2, w.slabs, w.dbp,
-                           w.ntiles2, gptr(L.off_rw), LossFinal{}, region_adam(L.off_rw, L.t_off_rw), st);
+    rc = mlp3_weight_grads(L.rw, w.sx_rw, R2 * L.rw.Kp1, w.h1r, w.h2r, w.dz3rw, w.dz2[0], w.dz1[0], R2, w.nsplit2, w.slabs[0], w.dbp[0],
+                           w.ntiles2, gptr(L.off_rw), LossFinal{}, region_adam(L.off_rw, L.t_off_rw), st2, precision,
+                           f16 ? w.eh1r : nullptr, f16 ? w.edz2[0] : nullptr);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(k_pre_fake_bwd, dim3((unsigned)cdiv(b * S, 256)), dim3(256), 0, st, r);
   MB_LAUNCH_OK("k_pre_fake_bwd");
   // ---- decoder ----
   {
-    Mlp3BwdArgs bw = pre_bwd_args(L.tr, Ttr, w.dz3tr, w.d1t, w.d2t, R4, w.dz2, w.dz1, w.dbp);
+    Mlp3BwdArgs bw = pre_bwd_args(L.tr, Ttr, w.dz3tr, w.d1t, w.d2t, R4, w.dz2[1], w.dz1[1], w.dbp[1], f16 ? w.edz2[1] : nullptr);
     bw.dx = w.dzt; bw.dx_c0 = 0; bw.dx_n = LATENT;
     rc = launch_mlp3_bwd(bw, NENS, true, 32, st);
+    if (!rc) rc = fork(1);
     if (rc) return rc;
-    rc = mlp3_weight_grads(L.tr, w.zt, R4 * LATENT, w.h1t, w.h2t, w.dz3tr, w.dz2, w.dz1, R4, w.nsplit4, w.slabs, w.dbp,
-                           w.ntiles4, gptr(L.off_tr), LossFinal{}, region_adam(L.off_tr, L.t_off_tr), st);
+    rc = mlp3_weight_grads(L.tr, w.zt, R4 * LATENT, w.h1t, w.h2t, w.dz3tr, w.dz2[1], w.dz1[1], R4, w.nsplit4, w.slabs[1], w.dbp[1],
+                           w.ntiles4, gptr(L.off_tr), LossFinal{}, region_adam(L.off_tr, L.t_off_tr), st2, precision,
+                           f16 ? w.eh1t : nullptr, f16 ? w.edz2[1] : nullptr);
     if (rc) return rc;
   }
   // ---- latent level + action encoder ----
@@ -782,19 +873,26 @@ static int pretrain_impl(int S, int A, int64_t b, int64_t b_global, int use_trg,
     const int64_t oz = use_trg ? L.off_za_trg : L.off_za_src;
     AdamTarget za{};
     if (opt.on) za = pre_adam_target(opt.blob + oz, nullptr, opt.m + oz, opt.v + oz, opt.t_za, opt.t_dev ? opt.t_dev + 1 : nullptr, opt.lr, 1.f);
-    hipLaunchKernelGGL(k_pre_za_reduce, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w.zap, w.nch, n, gptr(oz), za);
+    rc = fork(2);                                    // (the action encoder's reduction + Adam feed nothing later either)
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pre_za_reduce, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st2, w.zap, w.nch, n, gptr(oz), za);
     MB_LAUNCH_OK("k_pre_za_reduce");
   }
   // ---- state encoder ----
   {
-    Mlp3BwdArgs bw = pre_bwd_args(L.enc, Tenc, w.dz3enc, w.d1e, w.d2e, R2, w.dz2, w.dz1, w.dbp);
+    Mlp3BwdArgs bw = pre_bwd_args(L.enc, Tenc, w.dz3enc, w.d1e, w.d2e, R2, w.dz2[2], w.dz1[2], w.dbp[2], f16 ? w.edz2[2] : nullptr);
     rc = launch_mlp3_bwd(bw, NENS, false, 32, st);
     if (rc) return rc;
-    rc = mlp3_weight_grads(L.enc, w.sx_enc, R2 * L.enc.Kp1, w.h1e, w.h2e, w.dz3enc, w.dz2, w.dz1, R2, w.nsplit2, w.slabs, w.dbp,
-                           w.ntiles2, gptr(L.off_enc), LossFinal{}, region_adam(L.off_enc, L.t_off_enc), st);
+    rc = mlp3_weight_grads(L.enc, w.sx_enc, R2 * L.enc.Kp1, w.h1e, w.h2e, w.dz3enc, w.dz2[2], w.dz1[2], R2, w.nsplit2, w.slabs[2], w.dbp[2],
+                           w.ntiles2, gptr(L.off_enc), LossFinal{}, region_adam(L.off_enc, L.t_off_enc), st, precision,
+                           f16 ? w.eh1e : nullptr, f16 ? w.edz2[2] : nullptr);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_pre_loss_final, dim3(1), dim3(256), 0, st, w.lossp, w.lo, r.inv_bg, S, r.ce, r.cr, loss_out);
+  if (PRE_SIDE_STREAM) {                             // the step ends when both streams have: the main one waits for the side one
+    if (hipEventRecord(side->join, st2) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess)
+      return fail(MOBODY_E_LAUNCH, "pre-training: join of the side stream failed");
+  }
+  hipLaunchKernelGGL(k_pre_loss_final, dim3(1), dim3(256), 0, st, w.lossp, w.lo, r.inv_bg, S, r.ce, r.cr, loss_out, loss_acc);
   MB_LAUNCH_OK("k_pre_loss_final");
   return 0;
 }
@@ -802,28 +900,31 @@ static int pretrain_impl(int S, int A, int64_t b, int64_t b_global, int use_trg,
 extern "C" int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, int use_trg, float encoder_loss_coef,
                                      const float* blob, const float* blob_T, const float* xenc, const float* act,
                                      const float* rew, const float* noise6, const float* noise7, uint32_t seed, uint32_t call,
-                                     float* grad, float* loss_out, float* workspace, void* stream) {
+                                     float* grad, float* loss_out, float* workspace, int precision, void* stream) {
   MB_REQUIRE(grad, "mobody_pretrain_grads: grad is null");
   return pretrain_impl(S, A, b, b_global, use_trg, encoder_loss_coef, blob, blob_T, xenc, act, rew, noise6, noise7, seed, call,
-                       nullptr, grad, PreOpt{}, loss_out, workspace, stream);
+                       nullptr, grad, PreOpt{}, loss_out, nullptr, workspace, precision, stream);
 }
 
 extern "C" int mobody_pretrain_update(int S, int A, int64_t b, int use_trg, float encoder_loss_coef, float* blob, float* blob_T,
                                       const float* xenc, const float* act, const float* rew, const float* noise6,
                                       const float* noise7, uint32_t seed, uint32_t call, const int64_t* call_dev, float* m,
                                       float* v, int64_t t_main, int64_t t_za, const int64_t* t_dev, float lr, float* loss_out,
-                                      float* workspace, void* stream) {
+                                      float* loss_acc, float* workspace, int precision, void* stream) {
   MB_REQUIRE(m && v, "mobody_pretrain_update: null pointer");
   MB_REQUIRE(t_dev != nullptr || (t_main >= 1 && t_za >= 1), "mobody_pretrain_update: step counts are 1-based");
   PreOpt o{1, blob, blob_T, m, v, t_main, t_za, t_dev, lr};
   return pretrain_impl(S, A, b, b, use_trg, encoder_loss_coef, blob, blob_T, xenc, act, rew, noise6, noise7, seed, call, call_dev,
-                       nullptr, o, loss_out, workspace, stream);
+                       nullptr, o, loss_out, loss_acc, workspace, precision, stream);
 }
 
 extern "C" int mobody_pretrain_adam(int S, int A, int use_trg, float* blob, float* blob_T, const float* grad, float* m,
-                                    float* v, int64_t t_main, int64_t t_za, float lr, float grad_scale, void* stream) {
+                                    float* v, int64_t t_main, int64_t t_za, float lr, float grad_scale, int precision,
+                                    void* stream) {
   MobodyPretrainLayout L;
   int rc = mobody_pretrain_layout(S, A, &L);
+  if (rc) return rc;
+  rc = pre_check_prec(precision, "mobody_pretrain_adam");
   if (rc) return rc;
   MB_REQUIRE(blob && blob_T && grad && m && v, "mobody_pretrain_adam: null pointer");
   MB_REQUIRE(t_main >= 1 && t_za >= 1, "mobody_pretrain_adam: step counts are 1-based");
@@ -831,7 +932,8 @@ extern "C" int mobody_pretrain_adam(int S, int A, int use_trg, float* blob, floa
   const MobodyMlpLayout* nets[3] = {&L.enc, &L.tr, &L.rw};
   const int64_t offs[3] = {L.off_enc, L.off_tr, L.off_rw}, toffs[3] = {L.t_off_enc, L.t_off_tr, L.t_off_rw};
   for (int k = 0; k < 3; ++k) {
-    const AdamTarget a = pre_adam_target(blob + offs[k], blob_T + toffs[k], m + offs[k], v + offs[k], t_main, nullptr, lr, grad_scale);
+    const AdamTarget a = pre_adam_target(blob + offs[k], blob_T + toffs[k], m + offs[k], v + offs[k], t_main, nullptr, lr, grad_scale,
+                                         precision);
     rc = launch_adam(a, grad + offs[k], *nets[k], st);
     if (rc) return rc;
   }

@@ -398,10 +398,11 @@ def dara_penalty(z_sas, z_sa, coef, reward=None, want_delta=False):
 # ------------------------------------------------------------------------------------------------
 # dynamics pre-training
 # ------------------------------------------------------------------------------------------------
-def pretrain_transpose(blob, S, A, out=None):
+def pretrain_transpose(blob, S, A, out=None, precision=0):
+    """T blob of the pre-training parameter blob; `precision` (0 / "f32" or 4 / "f16x2") = the mode it will be trained in."""
     L = _lib.pretrain_layout(S, A)
     bt = out if out is not None else torch.zeros(L.t_total_floats, dtype=torch.float32, device=blob.device)
-    check(load().mobody_pretrain_transpose(S, A, ptr(blob), ptr(bt), cur_stream()), "mobody_pretrain_transpose")
+    check(load().mobody_pretrain_transpose(S, A, ptr(blob), ptr(bt), prec_id(precision), cur_stream()), "mobody_pretrain_transpose")
     return bt
 
 
@@ -427,24 +428,24 @@ def pretrain_gather(state, action, next_state, reward, idx, start, b, out=None, 
 
 
 def pretrain_grads(S, A, b, use_trg, encoder_loss_coef, blob, blob_T, xenc, act, rew, grad, loss_out, ws, noise6=None,
-                   noise7=None, seed=0, call=0, b_global=None):
+                   noise7=None, seed=0, call=0, b_global=None, precision=0):
     check(load().mobody_pretrain_grads(S, A, b, b if b_global is None else b_global, int(bool(use_trg)),
                                        float(encoder_loss_coef), ptr(blob), ptr(blob_T), ptr(xenc), ptr(act), ptr(rew),
                                        ptr(noise6), ptr(noise7), seed, call, ptr(grad), ptr(loss_out), ptr(ws),
-                                       cur_stream()), "mobody_pretrain_grads")
+                                       prec_id(precision), cur_stream()), "mobody_pretrain_grads")
 
 
 def pretrain_update(S, A, b, use_trg, encoder_loss_coef, blob, blob_T, xenc, act, rew, m, v, t_main, t_za, lr, loss_out, ws,
-                    noise6=None, noise7=None, seed=0, call=0, call_dev=None, t_dev=None):
+                    noise6=None, noise7=None, seed=0, call=0, call_dev=None, t_dev=None, precision=0, loss_acc=None):
     check(load().mobody_pretrain_update(S, A, b, int(bool(use_trg)), float(encoder_loss_coef), ptr(blob), ptr(blob_T), ptr(xenc),
                                         ptr(act), ptr(rew), ptr(noise6), ptr(noise7), seed, call, ptr(call_dev), ptr(m), ptr(v),
-                                        t_main, t_za, ptr(t_dev), float(lr), ptr(loss_out), ptr(ws), cur_stream()),
+                                        t_main, t_za, ptr(t_dev), float(lr), ptr(loss_out), ptr(loss_acc), ptr(ws), prec_id(precision), cur_stream()),
           "mobody_pretrain_update")
 
 
-def pretrain_adam(S, A, use_trg, blob, blob_T, grad, m, v, t_main, t_za, lr, grad_scale=1.0):
+def pretrain_adam(S, A, use_trg, blob, blob_T, grad, m, v, t_main, t_za, lr, grad_scale=1.0, precision=0):
     check(load().mobody_pretrain_adam(S, A, int(bool(use_trg)), ptr(blob), ptr(blob_T), ptr(grad), ptr(m), ptr(v), t_main,
-                                      t_za, float(lr), float(grad_scale), cur_stream()), "mobody_pretrain_adam")
+                                      t_za, float(lr), float(grad_scale), prec_id(precision), cur_stream()), "mobody_pretrain_adam")
 
 
 def dyn_validate(blob, S, A, obs, act, next_obs, rew, use_trg, ws=None):

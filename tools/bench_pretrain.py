@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--S", type=int, default=17); ap.add_argument("--A", type=int, default=6)
     ap.add_argument("--b", type=int, default=256); ap.add_argument("--rows", type=int, default=200000)
     ap.add_argument("--steps", type=int, default=300); ap.add_argument("--no_cpu", action="store_true")
+    ap.add_argument("--mfma", default="f16x2", choices=["f32", "f16x2"])
     args = ap.parse_args()
     from mobody_amd import engine, synthetic
     from mobody_amd.algo.dynamics.mobody_dynamics import MOBODYEnsembleDynamics
@@ -37,7 +38,8 @@ def main():
     S, A, b = args.S, args.A, args.b
     dev = torch.device("cuda:0")
     task = "walker2d-medium-v2" if S == 17 else "ant-medium-v2" if S == 111 else "pen-human-v1"
-    cfg = engine.default_config(S, A, no_vae=0, inverse_sep_reward_loss=0, train_together=0, train_with_src_threshold=1, dynamics_lr=1e-3)
+    cfg = engine.default_config(S, A, no_vae=0, inverse_sep_reward_loss=0, train_together=0, train_with_src_threshold=1, dynamics_lr=1e-3,
+                                mfma=args.mfma)
     m = MOBODYModule(S, A, 256, 7, 5, device=dev, config=cfg)
     dyn = MOBODYEnsembleDynamics(cfg, m, None, None, get_termination_fn(task), penalty_coef=0.1, rng="device", seed=1)
     g = torch.Generator().manual_seed(0)
