@@ -130,11 +130,24 @@ class MOBODYEnsembleDynamics(object):
     # ------------------------------------------------------------------ pre-training (mobody_dynamics.py:594-653,731-978,1113-1156)
     def _check_pretrain_config(self):
         cfg = self.config
-        if cfg.get("no_vae") or cfg.get("inverse_sep_reward_loss") or cfg.get("latent_reward") or cfg.get("train_together"):
-            raise NotImplementedError("no_vae / inverse_sep_reward_loss / latent_reward / train_together are ablations "
+        if cfg.get("inverse_sep_reward_loss") or cfg.get("latent_reward") or cfg.get("train_together"):
+            raise NotImplementedError("inverse_sep_reward_loss / latent_reward / train_together are ablations "
                                       "outside the accelerated pre-training path (reference defaults are 0)")
         if cfg.get("train_with_src_threshold", 1) != 1:
             raise NotImplementedError("train_with_src_threshold != 1 (data_augmentation) is outside the accelerated path")
+
+    def _enc_coef(self):
+        """Weight of encoder_loss in the step's loss.  config['no_vae'] = 1 (mobody_dynamics.py:616-635): the reference neither
+        evaluates nor adds encoder_loss -- the same gradients as weight 0 here (the reconstruction / KL / latent-consistency
+        terms enter every gradient through this factor only) -- and reports 0 for its three numbers (_stats)."""
+        return 0.0 if self.config.get("no_vae") else self.encoder_loss_coef
+
+    def _stats(self, t):
+        """(loss, transition, encoder, recon, kl) as learn() returns them.  Under no_vae the last three are 0 (:632-635) and
+        the second equals the first: `loss = transition_loss` aliases the tensor, `loss += reward_loss` (:641) adds in place,
+        so the reference's transition_loss.item() is the total (pinned by fixture g12_pretrain_walker_novae)."""
+        t = tuple(float(x) for x in t)
+        return (t[0], t[0], 0.0, 0.0, 0.0) if self.config.get("no_vae") else t
 
     def _lr(self):
         o = self.optim                                    # torch.optim.Adam(model.parameters(), lr=dynamics_lr) in the reference
@@ -161,7 +174,7 @@ class MOBODYEnsembleDynamics(object):
                 n6, n7 = n6[:, :, lo_rel:lo_rel + b].contiguous(), n7[:, lo_rel:lo_rel + b].contiguous()
         world, _ = self._world()
         if b > 0:
-            ops.pretrain_grads(S, A, b, use_trg, self.encoder_loss_coef, st["blob"], st["blob_T"], xenc, act, rew, st["grad"],
+            ops.pretrain_grads(S, A, b, use_trg, self._enc_coef(), st["blob"], st["blob_T"], xenc, act, rew, st["grad"],
                                self._pre_loss, ws, noise6=n6, noise7=n7,
                                seed=(self.seed + 77 + dp.rank_salt()) & 0xFFFFFFFF, call=self._train_calls, b_global=b_global,
                                precision=self.train_precision)
@@ -202,7 +215,7 @@ class MOBODYEnsembleDynamics(object):
         if self.train_noise_fn is not None:
             n6, n7 = self.train_noise_fn(b)
         st["t_main"] += 1; st["t_za"][bool(use_trg)] += 1
-        ops.pretrain_update(S, A, b, use_trg, self.encoder_loss_coef, st["blob"], st["blob_T"], xenc, act, rew, st["m"], st["v"],
+        ops.pretrain_update(S, A, b, use_trg, self._enc_coef(), st["blob"], st["blob_T"], xenc, act, rew, st["m"], st["v"],
                             st["t_main"], st["t_za"][bool(use_trg)], self._lr(), self._pre_loss, ws, noise6=n6,
                             noise7=n7, seed=(self.seed + 77) & 0xFFFFFFFF, call=self._train_calls, precision=self.train_precision,
                             loss_acc=acc)
@@ -221,7 +234,7 @@ class MOBODYEnsembleDynamics(object):
         # every pointer and scalar the captured launches bake in: a graph replayed after any of them moved (a reloaded model,
         # a second train() call, a changed learning rate) would read freed memory or the old constant without any error
         key = (d, b, idx.shape[1], idx.data_ptr(), ws.data_ptr(), self._pre_ctr.data_ptr(), self._pre_acc.data_ptr(),
-               self._pre_loss.data_ptr(), float(self._lr()), float(self.encoder_loss_coef), int(self.seed), self.train_precision) \
+               self._pre_loss.data_ptr(), float(self._lr()), float(self._enc_coef()), int(self.seed), self.train_precision) \
             + tuple(t.data_ptr() for t in data) + tuple(st[k].data_ptr() for k in ("blob", "blob_T", "m", "v"))
         c = self._pre_ctr                                  # [batch index, call, t_main, t_za]: one launch advances all four
         c.copy_(torch.tensor([-1, self._train_calls, st["t_main"], st["t_za"][d]], dtype=torch.int64), non_blocking=False)
@@ -233,7 +246,7 @@ class MOBODYEnsembleDynamics(object):
             def body():
                 ops.counter_add(c, 1)
                 ops.pretrain_gather(data[0], data[1], data[2], data[3], idx, 0, b, out=bufs, start_dev=c[0:1])
-                ops.pretrain_update(S, A, b, d, self.encoder_loss_coef, st["blob"], st["blob_T"], bufs[0], bufs[1], bufs[2],
+                ops.pretrain_update(S, A, b, d, self._enc_coef(), st["blob"], st["blob_T"], bufs[0], bufs[1], bufs[2],
                                     st["m"], st["v"], 1, 1, self._lr(), self._pre_loss, ws,
                                     seed=(self.seed + 77) & 0xFFFFFFFF, call=0, call_dev=c[1:2], t_dev=c[2:4],
                                     precision=self.train_precision, loss_acc=self._pre_acc)
@@ -269,7 +282,7 @@ class MOBODYEnsembleDynamics(object):
             r = step(k * batch_size, min(batch_size, n - k * batch_size), acc)
             if r is not None:                             # (None: the step's own last launch accumulated onto `acc`)
                 acc += r
-        return tuple(float(x) for x in (acc / max(n_batch, 1)).tolist())
+        return self._stats((acc / max(n_batch, 1)).tolist())
 
     def _shard(self, start, rows):
         """Rows of one batch owned by this rank (data parallel: contiguous slices, b_global = rows)."""
@@ -319,7 +332,7 @@ class MOBODYEnsembleDynamics(object):
                 self.total_steps += 1
                 acc += step(n_full * batch_size, n - n_full * batch_size)
                 n_batch += 1
-            return tuple(float(x) for x in (acc / n_batch).tolist())
+            return self._stats((acc / n_batch).tolist())
         return self._learn_loop(n, batch_size, step)
 
     @torch.no_grad()

@@ -588,11 +588,11 @@ class NoiseTap:
 PRE_CFG = dict(DYN_CFG, no_vae=0, inverse_sep_reward_loss=0, train_together=0, train_with_src_threshold=1)
 
 
-def make_dyn_trainer(S, A, seed, lr=1e-3):
+def make_dyn_trainer(S, A, seed, lr=1e-3, **cfg_over):
     m, p = load_dyn(S, A, seed, 0, 0.85)
-    m.config = dict(PRE_CFG)
+    m.config = dict(PRE_CFG, **cfg_over)
     opt = torch.optim.Adam(m.parameters(), lr=lr)                 # train_mobody.py:801-804
-    dyn = MOBODYEnsembleDynamics(dict(PRE_CFG), m, opt, None, get_termination_fn("walker2d-medium-v2"), penalty_coef=0.1)
+    dyn = MOBODYEnsembleDynamics(dict(PRE_CFG, **cfg_over), m, opt, None, get_termination_fn("walker2d-medium-v2"), penalty_coef=0.1)
     dyn.total_steps = 0
     return dyn, m, p
 
@@ -602,9 +602,11 @@ def g12():
     :300-330, transition_loss :337-347, reward_loss :349-384): the call sequence src, trg, src, trg pins the losses,
     every gradient, the per-parameter Adam step counts (za_src* only steps on source batches, za_trg* on target ones,
     decoders and saved_* never) and the post-step parameters."""
-    for tag, S, A, b, seed in (("walker", 17, 6, 24, 211), ("pen", 45, 24, 20, 213)):
-        dyn, m, p = make_dyn_trainer(S, A, seed)
-        out = dict(S=S, A=A, b=b, seed=seed, alive_val=0.85, wsum=gi.checksum(p), noise_seed=1200 + seed, lr=1e-3)
+    # "walker_novae": the same walker run with config no_vae = 1 (:616-635: encoder_loss is neither evaluated nor added, its
+    # three reported numbers are 0; only the transition / reward terms draw reparameterisation noise: 3 draws per step, not 7)
+    for tag, S, A, b, seed, over in (("walker", 17, 6, 24, 211, {}), ("pen", 45, 24, 20, 213, {}), ("walker_novae", 17, 6, 24, 211, dict(no_vae=1))):
+        dyn, m, p = make_dyn_trainer(S, A, seed, **over)
+        out = dict(S=S, A=A, b=b, seed=seed, alive_val=0.85, wsum=gi.checksum(p), noise_seed=1200 + seed, lr=1e-3, no_vae=int(over.get("no_vae", 0)))
         with NoiseTap(1200 + seed) as tap, CudaAlias():
             for step, use_trg in enumerate((False, True, False, True)):
                 rows = gi.pretrain_batch(3000 + 10 * seed + step, b, S, A)       # per-member rows [7,b,.]

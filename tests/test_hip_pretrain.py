@@ -55,12 +55,12 @@ class Trainer:
         self.zero2 = {k: torch.zeros(7, 32, 32, device=dev) for k in ("za_src2.weight", "za_trg2.weight")}
         self.zero2.update({k: torch.zeros(7, 1, 32, device=dev) for k in ("za_src2.bias", "za_trg2.bias")})
 
-    def grads(self, rows, noise, use_trg, b_global=None):
+    def grads(self, rows, noise, use_trg, b_global=None, enc_coef=1.0):
         td = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.dev)
         s, a, s2, r = rows
         xenc = td(np.concatenate([s, s2], 1)); act = td(a); rew = td(r[..., 0])
         n6 = td(np.stack(noise[:6])); n7 = td(noise[6])
-        self.ops.pretrain_grads(self.S, self.A, s.shape[1], use_trg, 1.0, self.blob, self.blob_T, xenc, act, rew, self.grad,
+        self.ops.pretrain_grads(self.S, self.A, s.shape[1], use_trg, enc_coef, self.blob, self.blob_T, xenc, act, rew, self.grad,
                                 self.loss, self.ws, noise6=n6, noise7=n7, b_global=b_global, precision=self.prec)
         torch.cuda.synchronize()
         return self.loss.cpu().numpy().copy()
@@ -108,6 +108,50 @@ def test_pretrain_steps_vs_reference_golden(tag, dev, mfma):
             params_close(gu.sub101(cur[k].cpu().numpy()), g[f"s{step}_p::{k}"], tr.lr)
     want_t = {x.split("=")[0]: int(x.split("=")[1]) for x in g["adam_steps"]}
     assert want_t["zs1.weight"] == tr.t_main and want_t["za_src1.weight"] == tr.t_za[False] and want_t["za_trg2.bias"] == tr.t_za[True]
+
+
+def test_pretrain_no_vae_vs_reference_golden(dev, mfma):
+    """config no_vae = 1 against the reference's own run with the flag (fixture g12_pretrain_walker_novae): the step with
+    encoder_loss weighted by 0 -- gradients, post-Adam parameters; and the mirror's learn() reports the reference's five
+    numbers (total, total again -- its in-place add aliases transition_loss --, 0, 0, 0)."""
+    from test_hip_train import params_close
+    from test_oracle_golden import novae_noise
+    g = gu.load("g12_pretrain_walker_novae")
+    S, A, b, seed = int(g["S"]), int(g["A"]), int(g["b"]), int(g["seed"])
+    p = gu.dyn_params_for(g)
+    tr = Trainer(p, S, A, b, dev, lr=float(g["lr"]), prec=mfma)
+    dyn, m = _mirror_dynamics(p, S, A, dev, dict(no_vae=1))
+    full2 = {k: torch.from_numpy(p[k]).to(dev) for k in ("za_src2.weight", "za_trg2.weight", "za_src2.bias", "za_trg2.bias")}
+    rng, rng2 = gu.gi.noise_stream(int(g["noise_seed"])), gu.gi.noise_stream(int(g["noise_seed"]))
+    td = lambda x: torch.from_numpy(x).to(dev)
+
+    def noise(bb):
+        nz = novae_noise(rng2, bb, S)
+        return td(np.stack(nz[:6])), td(nz[6])
+
+    dyn.train_noise_fn = noise
+    for step, use_trg in enumerate((False, True, False, True)):
+        rows = gu.gi.pretrain_batch(3000 + 10 * seed + step, b, S, A)
+        losses = tr.grads(rows, novae_noise(rng, b, S), use_trg, enc_coef=0.0)
+        want = g[f"s{step}_losses"]
+        close(losses[0], want[0], rtol=2e-5, atol=1e-6)
+        has = [str(x) for x in g[f"s{step}_has_grad"]]
+        got = tr.unpack(tr.grad)
+        scale = {}
+        for k in has:
+            sn = SUBNET[k[:2]]
+            scale[sn] = max(scale.get(sn, 0.0), float(np.abs(g[f"s{step}_g::{k}"]).max()))
+        for k in has:
+            close(gu.sub101(got[k].cpu().numpy()), g[f"s{step}_g::{k}"], rtol=1e-5, atol=1e-5 * scale[SUBNET[k[:2]]])
+        tr.apply(use_trg)
+        cur = tr.unpack(tr.blob, full2)
+        for k in cur:
+            params_close(gu.sub101(cur[k].cpu().numpy()), g[f"s{step}_p::{k}"], tr.lr)
+        stats = dyn.learn(use_trg, *[torch.from_numpy(x) for x in rows], b, 0.01)
+        close(np.array(stats), want, rtol=2e-5, atol=1e-6)
+    sd = m.state_dict()
+    for k in cur:
+        params_close(gu.sub101(sd[k].cpu().numpy()), g[f"s3_p::{k}"], tr.lr)
 
 
 @pytest.mark.parametrize("S,A,b", [(17, 6, 1), (17, 6, 33), (17, 6, 256), (111, 8, 40), (45, 24, 65)])
@@ -206,8 +250,8 @@ def _mirror_dynamics(p, S, A, dev, cfg_over=None):
     from mobody_amd.algo.dynamics.mobody_module import MOBODYModule
     from mobody_amd.algo.dynamics.mobody_dynamics import MOBODYEnsembleDynamics
     from mobody_amd.algo.mb_utils.terminal_funs import get_termination_fn
-    cfg = gu.policy_cfg(S, A, no_vae=0, inverse_sep_reward_loss=0, train_together=0, train_with_src_threshold=1,
-                        dynamics_lr=1e-3, **(cfg_over or {}))
+    cfg = gu.policy_cfg(S, A, **dict(dict(no_vae=0, inverse_sep_reward_loss=0, train_together=0, train_with_src_threshold=1,
+                                          dynamics_lr=1e-3), **(cfg_over or {})))
     m = MOBODYModule(S, A, 256, 7, 5, device=dev, config=cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()}, strict=False)
     return MOBODYEnsembleDynamics(cfg, m, None, None, get_termination_fn("walker2d-medium-v2"), penalty_coef=0.1), m

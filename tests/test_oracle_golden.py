@@ -354,3 +354,40 @@ def test_g12_dynamics_pretraining_steps(tag):
             close(gu.sub101(v.numpy()), g[f"s{step}_p::{k}"], rtol=1e-5, atol=2e-6)
     want = dict(x.split("=") for x in g["adam_steps"])
     assert {k: int(v) for k, v in want.items()} == st.t
+
+
+def novae_noise(rng, b, S):
+    """config no_vae = 1: the reference draws three tensors per step -- transition_loss's sample (z5 in the seven-draw
+    order), reward_loss's (z6) and the fake-next-state noise; the four encoder_loss samples are never drawn (zeros here:
+    every term they feed is weighted by 0)."""
+    z = np.zeros((7, b, 16), np.float32)
+    z5, z6 = (rng.standard_normal((7, b, 16)).astype(np.float32) for _ in range(2))
+    return [z, z, z, z, z5, z6, rng.standard_normal((7, b, S)).astype(np.float32)]
+
+
+def test_g12_pretraining_steps_no_vae():
+    """The no_vae ablation (mobody_dynamics.py:616-635: loss = transition_loss + reward_loss, encoder_loss neither evaluated
+    nor added, reported as 0) is the default step with encoder_loss weighted by 0: losses, gradients, Adam steps."""
+    g = gu.load("g12_pretrain_walker_novae")
+    assert int(g["no_vae"]) == 1
+    S, A, b, seed = int(g["S"]), int(g["A"]), int(g["b"]), int(g["seed"])
+    p = gu.dyn_params_for(g)
+    st = O.DynTrainState(p, lr=float(g["lr"]))
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    shapes = [tuple(int(x) for x in s.split(",")) for s in g["noise_shapes"]]
+    assert shapes[:3] == [(7, b, 16), (7, b, 16), (7, b, S)] and len(shapes) == 12
+    for step, use_trg in enumerate((False, True, False, True)):
+        rows = gu.gi.pretrain_batch(3000 + 10 * seed + step, b, S, A)
+        out = O.dyn_learn_step(st, *rows, novae_noise(rng, b, S), use_trg, encoder_loss_coef=0.0)
+        want = g[f"s{step}_losses"]
+        # (`loss = transition_loss` aliases the tensor and `loss += reward_loss` adds in place, :631,641: the "transition"
+        #  number the reference reports under no_vae is the total loss)
+        close(np.array([out["losses"][0], out["losses"][0]]), want[:2], rtol=2e-5, atol=1e-6)
+        assert list(want[2:]) == [0.0, 0.0, 0.0]
+        has = [str(x) for x in g[f"s{step}_has_grad"]]
+        scale = max(float(np.abs(g[k]).max()) for k in g if k.startswith(f"s{step}_g::"))
+        for k in has:
+            gr = out["grads"][k].numpy()
+            close(gu.sub101(gr), g[f"s{step}_g::{k}"], rtol=1e-4, atol=1e-5 * scale)
+        for k, v in st.p.items():
+            close(gu.sub101(v.numpy()), g[f"s{step}_p::{k}"], rtol=1e-5, atol=2e-6)
