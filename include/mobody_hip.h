@@ -425,6 +425,11 @@ int mobody_pretrain_update(int S, int A, int64_t b, int use_trg, float encoder_l
 int mobody_pretrain_adam(int S, int A, int use_trg, float* blob, float* blob_T, const float* grad, float* m, float* v,
                          int64_t t_main, int64_t t_za, float lr, float grad_scale, int precision, void* stream);
 
+/* Adam step of ONE action encoder only (blob layout, its own 1-based step count): the second encoder of a learn_src_trg step
+ * (config train_together = 1, :521-590 -- the summed source + target loss moves both, mobody_pretrain_adam steps one). */
+int mobody_pretrain_za_adam(int S, int A, int use_trg, float* blob, const float* grad, float* m, float* v, int64_t t_za,
+                            float lr, float grad_scale, void* stream);
+
 /* validate() (:1113-1140) on an inference blob (mobody_dyn_layout): out[0..6] = per-member mean_{b,d}(mean_e - s')^2,
  * out[7..13] = per-member mean_b (r_mu_e(s, a, mean_e) - r)^2.  Workspace floats: mobody_dyn_validate_workspace. */
 int64_t mobody_dyn_validate_workspace(int S, int A, int64_t B);

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "mobody_pretrain_grads": (C.c_int, [C.c_int, C.c_int, i64, i64, C.c_int, f32, vp, vp, vp, vp, vp, vp, vp, u32, u32,
                                         vp, vp, vp, C.c_int, vp]),
     "mobody_pretrain_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, i64, i64, f32, f32, C.c_int, vp]),
+    "mobody_pretrain_za_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, i64, f32, f32, vp]),
     "mobody_dyn_validate_workspace": (i64, [C.c_int, C.c_int, i64]),
     "mobody_dyn_validate": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp]),
 }

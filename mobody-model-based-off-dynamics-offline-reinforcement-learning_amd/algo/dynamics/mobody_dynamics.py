@@ -130,9 +130,11 @@ class MOBODYEnsembleDynamics(object):
     # ------------------------------------------------------------------ pre-training (mobody_dynamics.py:594-653,731-978,1113-1156)
     def _check_pretrain_config(self):
         cfg = self.config
-        if cfg.get("inverse_sep_reward_loss") or cfg.get("latent_reward") or cfg.get("train_together"):
-            raise NotImplementedError("inverse_sep_reward_loss / latent_reward / train_together are ablations "
-                                      "outside the accelerated pre-training path (reference defaults are 0)")
+        if cfg.get("inverse_sep_reward_loss") or cfg.get("latent_reward"):
+            raise NotImplementedError("inverse_sep_reward_loss / latent_reward are ablations outside the accelerated "
+                                      "pre-training path (reference defaults are 0)")
+        if cfg.get("train_together") and self._world()[0] > 1:
+            raise NotImplementedError("train_together = 1 is supported on one GPU (learn_src_trg is not sharded)")
         if cfg.get("train_with_src_threshold", 1) != 1:
             raise NotImplementedError("train_with_src_threshold != 1 (data_augmentation) is outside the accelerated path")
 
@@ -290,6 +292,80 @@ class MOBODYEnsembleDynamics(object):
         lo, hi = rows * rank // world, rows * (rank + 1) // world
         return start + lo, hi - lo
 
+    # ---- config['train_together'] = 1: learn_src_trg, mobody_dynamics.py:521-590 ------------------------------------------
+    def _learn_src_trg_batch(self, src, trg):
+        """One optimizer step on loss(source batch) + loss(target batch); src / trg = (xenc, act, rew, b).  The target
+        batch's encoder_loss is weighted 1 x encoder_loss_coef here (:571), not learn()'s 5 x -- the kernels apply 5 x to a
+        target batch, so it is called with a fifth of the coefficient; the two gradient blobs are summed (the shared nets
+        get both contributions, each action encoder its own) and ONE Adam step moves everything, both encoders included.
+        Returns the two device loss vectors (source, target)."""
+        m = self.model
+        st = m.train_state(self.train_precision)
+        if "grad2" not in st:
+            st["grad2"] = torch.zeros_like(st["grad"])
+            self._pre_loss2 = torch.zeros_like(self._pre_loss)
+        S, A = m.obs_dim, m.action_dim
+        st["grad"].zero_(); st["grad2"].zero_()
+        for (xenc, act, rew, b), d, grad, out, coef in ((src, False, st["grad"], self._pre_loss, self._enc_coef()),
+                                                       (trg, True, st["grad2"], self._pre_loss2, self._enc_coef() / 5.0)):
+            self._train_calls += 1
+            n6 = n7 = None
+            if self.train_noise_fn is not None:           # the reference draws the source batch's seven tensors, then the target's
+                n6, n7 = self.train_noise_fn(b)
+            ops.pretrain_grads(S, A, b, d, coef, st["blob"], st["blob_T"], xenc, act, rew, grad, out, self._ws_for(b),
+                               noise6=n6, noise7=n7, seed=(self.seed + 77) & 0xFFFFFFFF, call=self._train_calls,
+                               precision=self.train_precision)
+        st["grad"] += st["grad2"]
+        st["t_main"] += 1; st["t_za"][False] += 1; st["t_za"][True] += 1
+        ops.pretrain_adam(S, A, True, st["blob"], st["blob_T"], st["grad"], st["m"], st["v"], st["t_main"], st["t_za"][True],
+                          self._lr(), precision=self.train_precision)
+        ops.pretrain_za_adam(S, A, False, st["blob"], st["grad"], st["m"], st["v"], st["t_za"][False], self._lr())
+        m.mark_trained()
+        return self._pre_loss, self._pre_loss2
+
+    def _learn_src_trg_loop(self, n_trg, batch_size, batch):
+        """learn_src_trg's loop over ceil(n_trg / batch_size) batches; batch(k) -> (src, trg) tuples.  Returns the reference's
+        five numbers: mean total loss, mean TARGET transition / encoder loss, nan (it averages a list it never fills, :589),
+        mean target KL."""
+        self.model.training = True
+        acc = torch.zeros(4, dtype=torch.float32, device=self.model.device)
+        n_batch = int(np.ceil(n_trg / batch_size))
+        for k in range(n_batch):
+            self.total_steps = getattr(self, "total_steps", 0) + 1
+            ls, lt = self._learn_src_trg_batch(*batch(k))
+            acc += torch.stack([ls[0] + lt[0], lt[1], lt[2], lt[4]])
+        a = (acc / max(n_batch, 1)).tolist()
+        return (float(a[0]), float(a[1]), float(a[2]), float("nan"), float(a[3]))
+
+    def learn_src_trg(self, use_trg_data, train_obss, train_actions, train_next_obss, train_rewards, train_obss_trg,
+                      train_actions_trg, train_next_obss_trg, train_rewards_trg, batch_size, logvar_loss_coef, trg_transition=None):
+        """mobody_dynamics.py:521-590 on per-member rows `[7, n, .]` of both domains (batch k = columns k bs .. (k + 1) bs of each)."""
+        self._check_pretrain_config()
+        dev = self.model.device
+        f = lambda x: torch.as_tensor(x, dtype=torch.float32).to(dev)
+        S_ = [f(train_obss), f(train_actions), f(train_next_obss), f(train_rewards).reshape(7, -1)]
+        T_ = [f(train_obss_trg), f(train_actions_trg), f(train_next_obss_trg), f(train_rewards_trg).reshape(7, -1)]
+
+        def rows(D, k):
+            sl = slice(k * batch_size, (k + 1) * batch_size)
+            s = D[0][:, sl]
+            return torch.cat([s, D[2][:, sl]], 1).contiguous(), D[1][:, sl].contiguous(), D[3][:, sl].contiguous(), s.shape[1]
+
+        return self._learn_src_trg_loop(T_[0].shape[1], batch_size, lambda k: (rows(S_, k), rows(T_, k)))
+
+    def _learn_src_trg_indexed(self, src, src_idx, trg, trg_idx, batch_size):
+        """learn_src_trg on device-resident data sets with [7, n] bootstrap index matrices (as _learn_indexed)."""
+        n_s, n_t = src_idx.shape[1], trg_idx.shape[1]
+
+        def gather(data, idx, n, k):
+            lo = k * batch_size
+            b = min(batch_size, n - lo)
+            assert b > 0, "learn_src_trg walks the source rows in step with the target batches: not enough source rows"
+            xenc, act, rew = ops.pretrain_gather(data[0], data[1], data[2], data[3], idx, lo, b)
+            return xenc, act, rew, b
+
+        return self._learn_src_trg_loop(n_t, batch_size, lambda k: (gather(src, src_idx, n_s, k), gather(trg, trg_idx, n_t, k)))
+
     def learn(self, use_trg_data, train_obss, train_actions, train_next_obss, train_rewards, batch_size, logvar_loss_coef,
               trg_transition=None):
         """mobody_dynamics.py:594-653: one pass over the per-member rows `[7, n, .]` in batches of `batch_size`.
@@ -406,16 +482,19 @@ class MOBODYEnsembleDynamics(object):
         while True:
             epoch += 1
             self.epoch = epoch
-            src_stats = self._learn_indexed(False, src_tr, src_idx, batch_size)              # :873-878
+            together = bool(self.config.get("train_together"))
+            src_stats = self._learn_indexed(False, src_tr, src_idx, batch_size)              # :873-878 (:855-860 when together)
+            if together:                                                                    # :853-880: one joint pass, no 3 x target
+                trg_stats = self._learn_src_trg_indexed(src_tr, src_idx, trg_tr, trg_idx, batch_size)
             src_val, _ = self.validate(False, *src_ho)
             src_holdout_loss = float(np.sort(src_val)[:m.num_elites].mean())
-            for _ in range(3):                                                              # :897-907
+            for _ in range(0 if together else 3):                                           # :897-907
                 trg_stats = self._learn_indexed(True, trg_tr, trg_idx, batch_size)
             trg_val, trg_enc = self.validate(True, *trg_ho)
             trg_holdout_loss = float(np.sort(trg_val)[:m.num_elites].mean())
             self.history.append(dict(epoch=epoch, src=src_stats, trg=trg_stats, src_holdout=src_holdout_loss,
                                      trg_holdout=trg_holdout_loss, src_val=src_val, trg_val=trg_val, trg_reward_val=trg_enc))
-            if writer is not None:                                                          # :890-894, 921-924
+            if writer is not None and not together:                                         # :890-894, 921-924 (the joint branch only prints)
                 writer.add_scalar("src_loss/dynamics_train_loss", src_stats[1], global_step=epoch)
                 writer.add_scalar("src_loss/dynamics_encoder_loss", src_stats[2], global_step=epoch)
                 writer.add_scalar("src_loss/dynamics_domain_loss", src_stats[3], global_step=epoch)
@@ -423,8 +502,9 @@ class MOBODYEnsembleDynamics(object):
                 writer.add_scalar("trg_loss/dynamics_train_loss", trg_stats[1], global_step=epoch)
                 writer.add_scalar("trg_loss/dynamics_encoder_loss", trg_stats[2], global_step=epoch)
                 writer.add_scalar("trg_loss/dynamics_holdout_loss", trg_holdout_loss, global_step=epoch)
-            src_idx.copy_(bc(self.shuffle_rows(src_idx).contiguous()))                      # :934-935 (in place: the captured
-            trg_idx.copy_(bc(self.shuffle_rows(trg_idx).contiguous()))                      #  graphs keep reading these tensors)
+            if not together:                                                                # (:943-944 sit inside the else branch)
+                src_idx.copy_(bc(self.shuffle_rows(src_idx).contiguous()))                  # :934-935 (in place: the captured
+                trg_idx.copy_(bc(self.shuffle_rows(trg_idx).contiguous()))                  #  graphs keep reading these tensors)
             indexes = []
             for i, new_loss, old_loss in zip(range(E), trg_val, trg_holdout_losses):        # :937-942
                 if (old_loss - new_loss) / old_loss > 0.01:

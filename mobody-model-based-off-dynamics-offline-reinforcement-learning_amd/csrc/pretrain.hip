@@ -945,6 +945,20 @@ extern "C" int mobody_pretrain_adam(int S, int A, int use_trg, float* blob, floa
   return 0;
 }
 
+extern "C" int mobody_pretrain_za_adam(int S, int A, int use_trg, float* blob, const float* grad, float* m, float* v,
+                                       int64_t t_za, float lr, float grad_scale, void* stream) {
+  MobodyPretrainLayout L;
+  int rc = mobody_pretrain_layout(S, A, &L);
+  if (rc) return rc;
+  MB_REQUIRE(blob && grad && m && v && t_za >= 1, "mobody_pretrain_za_adam: null pointer or step count < 1");
+  const int64_t oz = use_trg ? L.off_za_trg : L.off_za_src;
+  const long long nz = (long long)NENS * L.za_member_floats;
+  const AdamTarget a = pre_adam_target(blob + oz, nullptr, m + oz, v + oz, t_za, nullptr, lr, grad_scale);
+  hipLaunchKernelGGL(k_pre_za_adam, dim3((unsigned)cdiv(nz, 256)), dim3(256), 0, as_stream(stream), a, grad + oz, nz);
+  MB_LAUNCH_OK("k_pre_za_adam");
+  return 0;
+}
+
 extern "C" int64_t mobody_dyn_validate_workspace(int S, int A, int64_t B) {
   (void)A;
   return (int64_t)NENS * B * S + (int64_t)NENS * B;

@@ -448,6 +448,12 @@ def pretrain_adam(S, A, use_trg, blob, blob_T, grad, m, v, t_main, t_za, lr, gra
                                       t_za, float(lr), float(grad_scale), prec_id(precision), cur_stream()), "mobody_pretrain_adam")
 
 
+def pretrain_za_adam(S, A, use_trg, blob, grad, m, v, t_za, lr, grad_scale=1.0):
+    """Adam step of one action encoder only (the second one of a learn_src_trg step)."""
+    check(load().mobody_pretrain_za_adam(S, A, int(bool(use_trg)), ptr(blob), ptr(grad), ptr(m), ptr(v), t_za, float(lr),
+                                         float(grad_scale), cur_stream()), "mobody_pretrain_za_adam")
+
+
 def dyn_validate(blob, S, A, obs, act, next_obs, rew, use_trg, ws=None):
     """validate(): out[0:7] per-member transition MSE, out[7:14] per-member reward MSE (device tensor)."""
     B = obs.shape[0]

@@ -571,6 +571,27 @@ def dyn_learn_step(st, obs, act, next_obs, rew, noise, use_trg, encoder_loss_coe
     return dict(losses=tuple(float(x.detach()) for x in losses), grads=grads)
 
 
+def dyn_learn_step_together(st, src_rows, trg_rows, noise_src, noise_trg, encoder_loss_coef=1.0, apply=True):
+    """One optimizer step of learn_src_trg (config train_together = 1, mobody_dynamics.py:521-590): the loss of a SOURCE batch
+    plus the loss of a TARGET batch whose encoder_loss is weighted 1 x encoder_loss_coef (not learn()'s 5 x, :571), one
+    backward, one Adam step in which BOTH action encoders move.  Draw order: the source batch's seven, then the target's.
+    Returns dict(losses=(total, trg transition, trg encoder, trg kl), grads)."""
+    pr = {k: v.detach().clone().requires_grad_(True) for k, v in st.p.items()}
+    ls = dyn_learn_losses(pr, *src_rows, noise_src, False, encoder_loss_coef)
+    lt = dyn_learn_losses(pr, *trg_rows, noise_trg, True, encoder_loss_coef / 5.0)
+    loss = ls[0] + lt[0]
+    names = list(pr)
+    gs = torch.autograd.grad(loss, [pr[k] for k in names], allow_unused=True)
+    grads = dict(zip(names, gs))
+    if apply:
+        for k, g in grads.items():
+            if g is None:
+                continue
+            st.t[k] += 1
+            adam_update(st.p[k], g, st.m[k], st.v[k], st.t[k], st.lr)
+    return dict(losses=(float(loss.detach()), float(lt[1].detach()), float(lt[2].detach()), float(lt[4].detach())), grads=grads)
+
+
 # --------------------------------------------------------------------------- #
 # A15: DARA reward penalty with the reference's softmax quirks
 # --------------------------------------------------------------------------- #

@@ -16,6 +16,7 @@ Usage:  python tests/golden/make_golden.py        (writes next to this file)
 """
 import os
 import sys
+import warnings
 import types
 
 import numpy as np
@@ -630,12 +631,40 @@ def g12():
         save(f"g12_pretrain_{tag}", **out)
 
 
-def g13():
+def g12t():
+    """config train_together = 1, one optimizer step per learn_src_trg() call (mobody_dynamics.py:521-590): a 24-row source
+    batch and a 17-row target batch per step, two steps -- total loss, the target batch's transition / encoder / KL numbers,
+    every gradient, post-step parameters, Adam step counts (both action encoders step)."""
+    S, A, bs, bt, seed = 17, 6, 24, 17, 231
+    dyn, m, p = make_dyn_trainer(S, A, seed, train_together=1)
+    out = dict(S=S, A=A, bs=bs, bt=bt, seed=seed, alive_val=0.85, wsum=gi.checksum(p), noise_seed=1400 + seed, lr=1e-3)
+    with NoiseTap(1400 + seed) as tap, CudaAlias():
+        for step in range(2):
+            src = gi.pretrain_batch(5000 + 10 * step, bs, S, A); trg = gi.pretrain_batch(5001 + 10 * step, bt, S, A)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")                                  # np.mean([]) of the never-filled recon list
+                res = dyn.learn_src_trg(False, *[torch.from_numpy(x) for x in src], *[torch.from_numpy(x) for x in trg], bs, 0.01)
+            out[f"s{step}_stats"] = np.array(res, np.float64)                    # total, trg transition, trg encoder, nan, trg kl
+            for k, v in m.named_parameters():
+                if v.grad is not None and not k.startswith(("max_", "min_", "elites")):
+                    out[f"s{step}_g::{k}"] = sub101(v.grad.numpy())
+                if ".saved_" not in k and not k.startswith(("max_", "min_", "elites", "za_de_")):
+                    out[f"s{step}_p::{k}"] = sub101(v.detach().numpy())
+            out[f"s{step}_has_grad"] = np.array(sorted(k for k, v in m.named_parameters() if v.grad is not None))
+    out["noise_shapes"] = np.array([",".join(map(str, sh)) for sh in tap.shapes])
+    st = dyn.optim.state_dict()["state"]
+    names = [k for k, _ in m.named_parameters()]
+    out["adam_steps"] = np.array([f"{names[i]}={int(float(v['step']))}" for i, v in st.items()])
+    print("together", [out[f"s{k}_stats"] for k in range(2)], "noise calls", len(tap.shapes))
+    save("g12_together_walker", **out)
+
+
+def g13(tag="g13_dyn_train", **cfg_over):
     """MOBODYEnsembleDynamics.train (mobody_dynamics.py:731-978) end to end on a tiny data set, max_epochs=2: holdout
     split (random_split), bootstrap indices (torch.randint), per-epoch learn(src) + 3 x learn(trg), validate, per-member
     early-stopping bookkeeping (update_save on > 1 % improvement), shuffle_rows, select_elites / set_elites / load_save."""
     S, A, bs = 17, 6, 32
-    dyn, m, p = make_dyn_trainer(S, A, 221)
+    dyn, m, p = make_dyn_trainer(S, A, 221, **cfg_over)
     src = gi.batch(901, 150, S, A); trg = gi.batch(902, 90, S, A)
     rec = []
     o_val = dyn.validate
@@ -656,7 +685,16 @@ def g13():
             out["sd::" + k] = sub101(v.numpy())
     print("train: elites", out["elites"], "validate calls", len(rec), "noise calls", len(tap.shapes), "steps", dyn.total_steps)
     print(np.stack(rec)[:, 0])
-    save("g13_dyn_train", **out)
+    save(tag, **out)
+
+
+def g13t():
+    """The same run with config train_together = 1 (:853-880: per epoch learn(source) then ONE learn_src_trg pass, no
+    reshuffle of the bootstrap indices)."""
+    import warnings as w_
+    with w_.catch_warnings():
+        w_.simplefilter("ignore")
+        g13("g13_dyn_train_together", train_together=1)
 
 
 def g14():

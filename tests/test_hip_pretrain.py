@@ -154,6 +154,65 @@ def test_pretrain_no_vae_vs_reference_golden(dev, mfma):
         params_close(gu.sub101(sd[k].cpu().numpy()), g[f"s3_p::{k}"], tr.lr)
 
 
+def test_pretrain_train_together_vs_reference_golden(dev, mfma):
+    """config train_together = 1, step level (fixture g12_together_walker: two learn_src_trg calls of the reference, a
+    24-row source batch + a 17-row target batch each): the mirror's learn_src_trg reports the reference's numbers and leaves
+    its parameters."""
+    from test_hip_train import params_close
+    g = gu.load("g12_together_walker")
+    S, A, bs, bt = int(g["S"]), int(g["A"]), int(g["bs"]), int(g["bt"])
+    p = gu.dyn_params_for(g)
+    dyn, m = _mirror_dynamics(p, S, A, dev, dict(train_together=1))
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    td = lambda x: torch.from_numpy(x).to(dev)
+
+    def noise(b):
+        nz = noise7(rng, b, S)
+        return td(np.stack(nz[:6])), td(nz[6])
+
+    dyn.train_noise_fn = noise
+    for step in range(2):
+        src = gu.gi.pretrain_batch(5000 + 10 * step, bs, S, A); trg = gu.gi.pretrain_batch(5001 + 10 * step, bt, S, A)
+        stats = dyn.learn_src_trg(False, *[torch.from_numpy(x) for x in src], *[torch.from_numpy(x) for x in trg], bs, 0.01)
+        want = g[f"s{step}_stats"]
+        assert np.isnan(stats[3]) and np.isnan(want[3])
+        close(np.array(stats)[[0, 1, 2, 4]], want[[0, 1, 2, 4]], rtol=2e-5, atol=1e-6)
+        sd = m.state_dict()
+        for k in g:
+            if k.startswith(f"s{step}_p::"):
+                params_close(gu.sub101(sd[k.split("::")[1]].cpu().numpy()), g[k], 1e-3)
+    st = m.train_state()
+    assert st["t_main"] == 2 and st["t_za"] == {False: 2, True: 2}
+
+
+def test_mirror_dynamics_train_together_vs_reference_golden(dev, mfma):
+    """MOBODYEnsembleDynamics.train with train_together = 1 end to end (fixture g13_dyn_train_together: the reference's own
+    run, 14 optimizer steps -- per epoch four learn() steps on the source rows, then three joint steps -- no reshuffle of the
+    bootstrap matrices): step and noise-draw counts, the four validate() results, elites."""
+    g = gu.load("g13_dyn_train_together")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    p = gu.dyn_params_for(g)
+    dyn, m = _mirror_dynamics(p, S, A, dev, dict(train_together=1))
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    td = lambda x: torch.from_numpy(x).to(dev)
+
+    def noise(b):
+        nz = noise7(rng, b, S)
+        return td(np.stack(nz[:6])), td(nz[6])
+
+    dyn.train_noise_fn = noise
+    src = gu.gi.batch(901, int(g["n_src"]), S, A); trg = gu.gi.batch(902, int(g["n_trg"]), S, A)
+    torch.manual_seed(int(g["rng_seed"])); np.random.seed(int(g["rng_seed"]))
+    dyn.train(tuple(torch.from_numpy(x) for x in src), tuple(torch.from_numpy(x) for x in trg), max_epochs=2, batch_size=bs)
+    assert dyn.total_steps == int(g["total_steps"]) and dyn._train_calls == int(g["n_noise"]) // 7
+    want = g["validate"]
+    got = []
+    for h in dyn.history:
+        got += [h["src_val"], h["trg_val"]]
+    close(np.array(got), want[:, 0], rtol=1e-4, atol=1e-8)
+    assert sorted(int(x) for x in m.elites.tolist()) == sorted(int(x) for x in g["elites"])
+
+
 @pytest.mark.parametrize("S,A,b", [(17, 6, 1), (17, 6, 33), (17, 6, 256), (111, 8, 40), (45, 24, 65)])
 def test_pretrain_grads_vs_oracle_shapes(S, A, b, dev, mfma):
     """Ragged / full batches and the ant / pen shapes against the oracle's autograd (same noise), source and target step."""

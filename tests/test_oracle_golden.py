@@ -391,3 +391,30 @@ def test_g12_pretraining_steps_no_vae():
             close(gu.sub101(gr), g[f"s{step}_g::{k}"], rtol=1e-4, atol=1e-5 * scale)
         for k, v in st.p.items():
             close(gu.sub101(v.numpy()), g[f"s{step}_p::{k}"], rtol=1e-5, atol=2e-6)
+
+
+def test_g12_pretraining_steps_train_together():
+    """config train_together = 1: two learn_src_trg steps (mobody_dynamics.py:521-590) -- a source batch and a target batch in
+    ONE loss (target encoder_loss weighted 1 x, not 5 x), one Adam step that moves both action encoders."""
+    g = gu.load("g12_together_walker")
+    S, A, bs, bt = int(g["S"]), int(g["A"]), int(g["bs"]), int(g["bt"])
+    p = gu.dyn_params_for(g)
+    st = O.DynTrainState(p, lr=float(g["lr"]))
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    shapes = [tuple(int(x) for x in s.split(",")) for s in g["noise_shapes"]]
+    assert shapes[:14] == [(7, bs, 16)] * 6 + [(7, bs, S)] + [(7, bt, 16)] * 6 + [(7, bt, S)]     # source draws, then target draws
+    for step in range(2):
+        src = gu.gi.pretrain_batch(5000 + 10 * step, bs, S, A); trg = gu.gi.pretrain_batch(5001 + 10 * step, bt, S, A)
+        out = O.dyn_learn_step_together(st, src, trg, _noise7(rng, bs, S), _noise7(rng, bt, S))
+        want = g[f"s{step}_stats"]
+        assert np.isnan(want[3])                                   # the reference averages a list it never fills
+        close(np.array(out["losses"]), want[[0, 1, 2, 4]], rtol=2e-5, atol=1e-6)
+        has = sorted(k for k, v in out["grads"].items() if v is not None)
+        assert has == [str(x) for x in g[f"s{step}_has_grad"]]
+        scale = max(float(np.abs(g[k]).max()) for k in g if k.startswith(f"s{step}_g::"))
+        for k in has:
+            close(gu.sub101(out["grads"][k].numpy()), g[f"s{step}_g::{k}"], rtol=1e-4, atol=1e-5 * scale)
+        for k, v in st.p.items():
+            close(gu.sub101(v.numpy()), g[f"s{step}_p::{k}"], rtol=1e-5, atol=2e-6)
+    want_t = dict(x.split("=") for x in g["adam_steps"])
+    assert {k: int(v) for k, v in want_t.items()} == st.t
