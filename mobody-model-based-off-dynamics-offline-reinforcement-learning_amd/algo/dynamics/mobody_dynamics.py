@@ -131,8 +131,10 @@ class MOBODYEnsembleDynamics(object):
     def _check_pretrain_config(self):
         cfg = self.config
         if cfg.get("inverse_sep_reward_loss") or cfg.get("latent_reward"):
-            raise NotImplementedError("inverse_sep_reward_loss / latent_reward are ablations outside the accelerated "
-                                      "pre-training path (reference defaults are 0)")
+            raise NotImplementedError("inverse_sep_reward_loss / latent_reward are ablations outside the accelerated pre-training "
+                                      "path (reference defaults are 0; with latent_reward = 1 the reference's own learn() raises "
+                                      "TypeError: reward_loss_with_latent calls encode_trg_action(action) without the state, "
+                                      "mobody_dynamics.py:409 against mobody_module.py:258)")
         if cfg.get("train_together") and self._world()[0] > 1:
             raise NotImplementedError("train_together = 1 is supported on one GPU (learn_src_trg is not sharded)")
         if cfg.get("train_with_src_threshold", 1) != 1:
