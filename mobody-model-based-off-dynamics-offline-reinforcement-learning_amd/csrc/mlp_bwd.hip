@@ -21,6 +21,10 @@
 #include "layers_bf.h"
 #include "train.h"
 
+#ifndef BWD_MASK_PREFETCH
+#define BWD_MASK_PREFETCH 1     // 0: fetch a layer's mask operand inside its epilogue (A/B aid)
+#endif
+
 namespace mobody {
 
 // Masked epilogue of a backward wide layer, in two parts around the barrier that separates the GEMM's LDS reads from the
@@ -32,19 +36,25 @@ namespace mobody {
 // are in flight together and cost one round trip.  Returns the lane's largest |dz| (the f16 mode's tile scale).
 // MASK: 0 = ReLU mask from the saved activations (h > 0), 1 = ReLU mask from the forward's sign words,
 //       2 = Swish: multiply by the saved derivative d = dy/dz (h points at save_d of the forward, mobody_module.py:9-15).
+// The mask operand of one layer for this lane: two sign words per 32-row tile (MASK == 1) or the 32 saved values per tile
+// (MASK 0: activations, 2: Swish derivatives).  It is requested BEFORE the GEMM whose epilogue consumes it (mask_fetch):
+// fetched inside the epilogue it put one L2 / HBM round trip (~1 us) between each GEMM and its epilogue in every workgroup of
+// the launch at the same moment (phase trace of a lone workgroup: mask epilogue 2.5 us of a 10.9 us backward).  All loads are
+// UNCONDITIONAL from clamped rows (see above).
 template <int MT, int MASK>
-__device__ __forceinline__ float wide_mask_apply(f32x16 (&acc)[MT][2], const float* __restrict__ h,
-                                                 const uint32_t* __restrict__ bits, int rows_here, float prescale) {
-  const int lane = lane_id(), w = wave_id();
-  const int i = lane & 31, hh = lane >> 5;
-  constexpr bool BITS = MASK == 1;
-  float hv[BITS ? 1 : MT][2][BITS ? 1 : 16];
-  uint32_t mw[MT][2];
-  if constexpr (BITS) {                            // two words per 32-row tile and lane instead of 32 activations
+struct MaskPre {
+  uint32_t w[MASK == 1 ? MT : 1][2];
+  float v[MASK == 1 ? 1 : MT][2][MASK == 1 ? 1 : 16];
+};
+template <int MT, int MASK>
+__device__ __forceinline__ void mask_fetch(MaskPre<MT, MASK>& p, const float* __restrict__ h, const uint32_t* __restrict__ bits,
+                                           int rows_here) {
+  const int lane = lane_id(), w = wave_id(), i = lane & 31, hh = lane >> 5;
+  if constexpr (MASK == 1) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int g = min(mt, (rows_here + 31) / 32 - 1);      // groups past the end of the batch have no words (their rows are masked)
-      mw[mt][0] = bits[g * HID + 64 * w + i]; mw[mt][1] = bits[g * HID + 64 * w + 32 + i];
+      p.w[mt][0] = bits[g * HID + 64 * w + i]; p.w[mt][1] = bits[g * HID + 64 * w + 32 + i];
     }
   } else {
     const float* hp = h + 64 * w + i;
@@ -53,10 +63,18 @@ __device__ __forceinline__ float wide_mask_apply(f32x16 (&acc)[MT][2], const flo
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = min(32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh, rows_here - 1);
-        hv[mt][0][r] = hp[row * HID];
-        hv[mt][1][r] = hp[row * HID + 32];
+        p.v[mt][0][r] = hp[row * HID];
+        p.v[mt][1][r] = hp[row * HID + 32];
       }
   }
+}
+
+template <int MT, int MASK>
+__device__ __forceinline__ float wide_mask_apply(f32x16 (&acc)[MT][2], const MaskPre<MT, MASK>& pre, int rows_here, float prescale) {
+  const int hh = lane_id() >> 5;
+  constexpr bool BITS = MASK == 1;
+  const auto& hv = pre.v;
+  const auto& mw = pre.w;
   float mx = 0.f;
   // full tile (wave uniform): no per-element row guard
   auto sweep = [&](auto guarded) {
@@ -193,7 +211,7 @@ __device__ __forceinline__ void bwd_seed(const Mlp3BwdArgs& a, float* Xs, float*
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { l0 += __shfl_xor(l0, o); l1 += __shfl_xor(l1, o); }
   if ((t & 63) == 0) { red[t >> 6] = l0; red[4 + (t >> 6)] = l1; }
-  __syncthreads();
+  lds_barrier();                                     // (LDS only: __syncthreads would also drain the dz3_out stores, ~1 us per tile)
   if (t == 0) {
     l0 = red[0] + red[1] + red[2] + red[3];
     l1 = red[4] + red[5] + red[6] + red[7];
@@ -234,6 +252,11 @@ __global__ __launch_bounds__(NTHREADS, (MT == 1 && MASK == 1) ? 3 : 2) void k_ml
   float* scr = reinterpret_cast<float*>(reinterpret_cast<char*>(Xs) + split_scr_offset<PMX, TB>());   // tile maximum (f16 mode)
 
   TR(0);
+  MaskPre<MT, MASK> mk1, mk2;                       // layer 2's operand now; layer 1's too when it is two words, else before its GEMM
+  if (BWD_MASK_PREFETCH) {
+    mask_fetch<MT, MASK>(mk2, h2, m2, rows_here);
+    if constexpr (BITS) mask_fetch<MT, MASK>(mk1, h1, m1, rows_here);
+  }
   // (split modes: the ring only serves the K = Np3 GEMM, two to four chunks -- three stages keep the kernel at 128 registers)
   WideRingT<(PM > 0 ? 3 : WIDE_RING)> ring;
   wide_prefetch(w3t, a.Np3, ring);                // weight fragments travel while the seed rows are fetched
@@ -259,7 +282,8 @@ __global__ __launch_bounds__(NTHREADS, (MT == 1 && MASK == 1) ? 3 : 2) void k_ml
   else wide_prefetch(w2t, HID, ring);             // next layer's first fragments overlap the mask epilogue
   int e2 = 0;
   {
-    const float mx = wide_mask_apply<MT, MASK>(acc, h2, m2, rows_here, 1.f);
+    if (!BWD_MASK_PREFETCH) mask_fetch<MT, MASK>(mk2, h2, m2, rows_here);
+    const float mx = wide_mask_apply<MT, MASK>(acc, mk2, rows_here, 1.f);
     if constexpr (PM == 4) f16_tile_max_put(mx, scr);
   }
   lds_barrier();
@@ -275,13 +299,15 @@ __global__ __launch_bounds__(NTHREADS, (MT == 1 && MASK == 1) ? 3 : 2) void k_ml
   lds_barrier();
   TR(3);
   // dh1 = dz2 * W2^T ; dz1 = dh1 * [h1 > 0]
+  if constexpr (!BITS) { if (BWD_MASK_PREFETCH) mask_fetch<MT, MASK>(mk1, h1, m1, rows_here); }
   wide_zero<MT>(acc);
   if constexpr (PM > 0) bf_gemm<MT, PMX, TB>(reinterpret_cast<const char*>(Xs), w2tp, acc, bring);
   else wide_gemm<MT>(Xs, w2t, HID, acc, ring);
   TR(4);
   NarrowRegs<(NT > 0 ? NT : 1)> br;
   if constexpr (DX && NT > 0) narrow_prefetch<NT>(w1t, 16 * NT, br);
-  wide_mask_apply<MT, MASK>(acc, h1, m1, rows_here, PM == 4 ? exp2i(-(e2 + F16_WSHIFT)) : 1.f);
+  if (!BWD_MASK_PREFETCH) mask_fetch<MT, MASK>(mk1, h1, m1, rows_here);
+  wide_mask_apply<MT, MASK>(acc, mk1, rows_here, PM == 4 ? exp2i(-(e2 + F16_WSHIFT)) : 1.f);
   lds_barrier();
   wide_store_colsum<MT, 0>(acc, Xs, dz1, rows_here, 0, cs);
   if (lane < 32) { dbp[64 * w + lane] = cs[0]; dbp[64 * w + 32 + lane] = cs[1]; }
@@ -412,9 +438,9 @@ __device__ __forceinline__ void wgrad_store(const WgradJob& jb, const WgradArgs&
         }
   };
   if (w < 2) sweep(false);
-  __syncthreads();
+  lds_barrier();
   if (w >= 2) sweep(true);
-  __syncthreads();
+  lds_barrier();
   float* slab = a.slabs + (long long)slice * a.slab_stride + jb.out_off + m * a.out_mstride;
   for (int idx = threadIdx.x; idx < TK * TN; idx += NTHREADS) {
     const int kk = idx / TN, nn = idx - kk * TN;
@@ -813,6 +839,8 @@ __global__ __launch_bounds__(256) void k_grad_reduce(GradReduceArgs a) {
     const long long o = j % a.L.member_floats;
     const bool is_bias = (o >= a.L.b1 && o < a.L.b1 + HID) || (o >= a.L.b2 && o < a.L.b2 + HID) || (o >= a.L.b3);
     if (is_bias) return;
+    // (requesting all 16 slab entries and the Adam state in one round trip instead of groups of four + one measured neutral at
+    //  c2 and -1 % on the pre-training step: not kept)
     float s = 0.f;
     int k = 0;
     for (; k + 4 <= a.nsplit; k += 4) {            // 4 independent loads in flight, summed in slab order

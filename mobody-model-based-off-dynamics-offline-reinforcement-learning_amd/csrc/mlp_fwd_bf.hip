@@ -14,6 +14,9 @@
 #ifndef FWD_L1_RING
 #define FWD_L1_RING 3
 #endif
+#ifndef FWD_LOAD2
+#define FWD_LOAD2 1            // 0: one tile_load per input source (A/B aid)
+#endif
 #ifndef FWD_F16_WAVES
 #define FWD_F16_WAVES 4
 #endif
@@ -36,11 +39,17 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
   WideRingT<FWD_L1_RING> ring;                  // layer 1 is K = 24 .. 120: a short ring keeps the kernel at 128 registers
   wide_prefetch(w1, a.Kp1, ring);
   int c0 = 0;
+  if (FWD_LOAD2 && RG == 1 && a.n[0] <= 32 && a.n[1] <= 32 && a.n[2] == 0) {       // state | action: both sources in one round trip
+    tile_load2<TB>(Xs, a.src[0] + m * a.src_ms[0] + row0 * a.ld[0], a.ld[0], a.n[0],
+                   a.n[1] > 0 ? a.src[1] + m * a.src_ms[1] + row0 * a.ld[1] : nullptr, a.ld[1], a.n[1], rows_here);
+    c0 = a.n[0] + a.n[1];
+  } else {
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    if (a.n[k] > 0) {
-      tile_load(Xs, c0, a.src[k] + m * a.src_ms[k] + row0 * a.ld[k], a.ld[k], a.n[k], 0, rows_here, TB);
-      c0 += a.n[k];
+    for (int k = 0; k < 3; ++k) {
+      if (a.n[k] > 0) {
+        tile_load(Xs, c0, a.src[k] + m * a.src_ms[k] + row0 * a.ld[k], a.ld[k], a.n[k], 0, rows_here, TB);
+        c0 += a.n[k];
+      }
     }
   }
   tile_zero_cols(Xs, c0, a.Kp1, TB);

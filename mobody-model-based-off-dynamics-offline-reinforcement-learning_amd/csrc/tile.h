@@ -417,6 +417,33 @@ __device__ __forceinline__ void tile_load(float* Xs, int col0, const float* __re
     }
   }
 }
+// Two sources of at most 32 columns each (state | action, the train step's inputs) in ONE round trip: thread t owns column
+// t & 31 of both and rows (t >> 5) + 8 u; every load of both sources is requested before the first LDS write (tile_load per
+// source is two dependent round trips -- the second source's loads sit behind the first one's stores -- ~1 us per forward
+// launch whose workgroups all wait at the same moment).  n1 may be 0 (one source: the second is not read).  TB = 32 or 64.
+template <int TB>
+__device__ __forceinline__ void tile_load2(float* Xs, const float* __restrict__ src0, int ld0, int n0,
+                                           const float* __restrict__ src1, int ld1, int n1, int rows) {
+  constexpr int U = TB / 8;
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+  const float* s1 = n1 > 0 ? src1 : src0;            // an absent second source re-reads the first (result unused)
+  const int l1 = n1 > 0 ? ld1 : ld0, m1 = n1 > 0 ? n1 : n0;
+  float v0[U], v1[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const size_t r = (size_t)min(r0 + 8 * u, rows - 1);
+    v0[u] = src0[r * ld0 + min(c, n0 - 1)];
+    v1[u] = s1[r * l1 + min(c, m1 - 1)];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int r = r0 + 8 * u;
+    const bool ok = r < rows;
+    if (c < n0) Xs[r * LDX + c] = ok ? v0[u] : 0.f;
+    if (c < n1) Xs[r * LDX + n0 + c] = ok ? v1[u] : 0.f;
+  }
+}
+
 __device__ __forceinline__ void tile_zero_cols(float* Xs, int c0, int c1, int bm = BM) {
   for (int r = threadIdx.x; r < bm; r += (int)blockDim.x)
     for (int c = c0; c < c1; ++c) Xs[r * LDX + c] = 0.f;

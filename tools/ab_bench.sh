@@ -1,0 +1,14 @@
+# usage (GPU box): bash tools/ab_bench.sh FILE.hip "flags A" "flags B" ...  -- c2 / c1 / pretrain step times of each variant on ONE box
+for F in "${@:2}"; do
+  bash tools/ab_build.sh $1 "$F" || exit 1
+  for rep in 1 2; do
+    python bench.py --no_cpu_baseline --no_mode_sweep > gpurun_out/ab_tmp.json 2>/dev/null
+    python -c "
+import json; d=json.load(open('gpurun_out/ab_tmp.json')); k=d['kernels']
+print('[$F] c2 %.4f ms  fwd %.1f bwd %.1f wgrad %.1f us' % (d['ms_per_step'], k['k_mlp3_fwd']['ms_per_step']*1e3, k['k_mlp3_bwd']['ms_per_step']*1e3, k['k_wgrad']['ms_per_step']*1e3))"
+  done
+  python bench.py --config c1 --no_cpu_baseline --no_mode_sweep > gpurun_out/ab_tmp.json 2>/dev/null; python -c "
+import json; d=json.load(open('gpurun_out/ab_tmp.json')); print('[$F] c1 %.4f ms' % d['ms_per_step'])"
+  python bench.py --config pretrain --no_cpu_baseline > gpurun_out/ab_tmp.json 2>/dev/null; python -c "
+import json; d=json.load(open('gpurun_out/ab_tmp.json')); print('[$F] pretrain %.4f ms' % d['ms_per_step'])"
+done

@@ -1,0 +1,9 @@
+set -e
+cd $GRAFT_REPO_ROOT
+MOBODY_TRACE=1 python - <<PY
+import sys
+sys.path.insert(0, "mobody-model-based-off-dynamics-offline-reinforcement-learning_amd/csrc")
+import build
+build.build(force=True, verbose=False)
+PY
+for mode in fwd critic actor; do echo "=== f16x2 $mode 2560 rows (one workgroup per CU)"; MOBODY_MFMA=f16x2 python tools/trace_mlp.py $mode 2560; done
