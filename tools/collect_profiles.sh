@@ -8,7 +8,7 @@ mkdir -p $O
 BENCH="python3 bench.py --steps 100 --warmup 10 --no_cpu_baseline --no_mode_sweep --graph 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o kt -- $BENCH > gpurun_out/${TAG}_bench_under_rocprof.json 2> $O/kt.err && cp $O/kt/kt_kernel_stats.csv gpurun_out/${TAG}_kernel_stats_bench_c2.csv
 echo "kernel trace done"
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_m -- python3 bench.py --steps 40 --warmup 3 --no_cpu_baseline --no_mode_sweep --graph 0 > /dev/null 2> $O/pmc_m.err && python tools/pmc_mfma.py $O/pmc_m gpurun_out/${TAG}_pmc_mfma.json | tail -12
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $O/pmc_m -- python3 bench.py --steps 40 --warmup 3 --no_cpu_baseline --no_mode_sweep --graph 0 > /dev/null 2> $O/pmc_m.err && python tools/pmc_mfma.py $O/pmc_m gpurun_out/${TAG}_pmc_mfma.json | tail -12
 echo "pmc mfma done"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -- python3 bench.py --steps 40 --warmup 3 --no_cpu_baseline --no_mode_sweep --graph 0 > /dev/null 2> $O/pmc_f.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -- python3 bench.py --steps 40 --warmup 3 --no_cpu_baseline --no_mode_sweep --graph 0 > /dev/null 2> $O/pmc_w.err
