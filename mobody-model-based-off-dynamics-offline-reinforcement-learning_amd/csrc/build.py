@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libmobody_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
+FLAGS += os.environ.get("MOBODY_EXTRA_FLAGS", "").split()   # A/B aid: e.g. MOBODY_EXTRA_FLAGS="-DBF_BUFFER_LOADS=0" python build.py --force
 if os.environ.get("MOBODY_TRACE") == "1":          # diagnostic build: phase timestamps in the MLP kernels (needs -fgpu-rdc
     FLAGS += ["-DMOBODY_TRACE", "-fgpu-rdc"]       # for the one trace buffer shared by the translation units)
 
