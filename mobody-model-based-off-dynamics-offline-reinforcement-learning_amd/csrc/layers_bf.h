@@ -19,7 +19,8 @@ __device__ __forceinline__ void relu_mask_words(f32x16 (&y)[MT][2], uint32_t* ma
     for (int nt = 0; nt < 2; ++nt) {
       uint32_t word = 0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) word |= (uint32_t)(y[mt][nt][r] > 0.f) << ((r & 3) + 8 * (r >> 2) + 4 * hh);
+      for (int r = 0; r < 16; ++r)                      // y is a ReLU output (>= +0, never -0): y > 0 <=> its bit pattern is non-zero --
+        word |= min(__float_as_uint(y[mt][nt][r]), 1u) << ((r & 3) + 8 * (r >> 2) + 4 * hh);   // v_min_u32 + v_lshl_or instead of cmp + cndmask + lshl_or
       word |= (uint32_t)__shfl_xor((int)word, 32);
       const int grp = MT * wave_rg() + mt;
       if (hh == 0 && grp < mask_groups) mask[grp * HID + 64 * wave_col() + 32 * nt + i] = word;
@@ -39,10 +40,31 @@ struct PlaneSave {
 // Row-major fp32 copy of a wide result held in accumulators to global memory (tile base dst, leading dimension 256): 32
 // coalesced dword stores per lane as ONE branch-free burst when the tile is full; the per-element row guard (v_cmp + exec
 // save / restore around every store) only on the batch's last, ragged tile.
+#ifndef ROWS_BUFFER_STORES
+#define ROWS_BUFFER_STORES 1
+#endif
 template <int MT>
 __device__ __forceinline__ void wide_store_rows(f32x16 (&acc)[MT][2], float* dst, bool full, int rows_here) {
+#if ROWS_BUFFER_STORES
+  // through a descriptor over the tile's REAL rows: a row past the end of the batch is out of range and the hardware drops
+  // its store (one code path for full and ragged tiles), and an address is one per-lane offset + a scalar row offset -- no
+  // 64-bit vector add per store (row offsets reach 31 KB, beyond the instruction's immediate field)
+  (void)full;
+  const int lane = lane_id();
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(dst, (unsigned)min(rows_here, 1024) * (unsigned)(HID * 4));   // (tiles hold <= 64 rows)
+  const int voff = ((32 * MT * wave_rg() + 4 * (lane >> 5)) * HID + 64 * wave_col() + (lane & 31)) * 4;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][r]), rs, voff,
+                                              ((32 * mt + (r & 3) + 8 * (r >> 2)) * HID + 32 * nt) * 4, 0);
+#else
   if (full) wide_foreach<MT>(acc, [&](int row, int col, float y) { dst[row * HID + col] = y; });
   else wide_foreach<MT>(acc, [&](int row, int col, float y) { if (row < rows_here) dst[row * HID + col] = y; });
+#endif
 }
 
 // Write the planes of a wide result held in accumulators (values y, scaled by 2^e in the f16 mode): four consecutive rows

@@ -87,6 +87,18 @@ template <int R>
 struct WideRingT { f32x4 r[R][2]; };
 using WideRing = WideRingT<WIDE_RING>;
 
+// A wave-uniform pointer as a buffer descriptor (records = bytes): loads through it take ONE per-lane 32-bit offset plus a scalar
+// offset, no 64-bit vector address arithmetic (the pointer is forced into scalar registers: kernels pass member bases that are
+// uniform by construction).
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  const void* base = (const void*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                   (unsigned int)__builtin_amdgcn_readfirstlane((int)a));
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// (fp32 weight fragments and the narrow layers' fragments keep plain pointer loads: through the descriptor c2 was neutral and the
+//  small launches -- c1, pre-training -- 2 % slower; the 64 16-byte loads per tile of the split core are where it pays, tile_bf.h)
 __device__ __forceinline__ void wide_ldb(const float* __restrict__ W, int Kp, int c, f32x4 (&b)[2]) {
   const int lane = lane_id();
   const int i = lane & 31, h = lane >> 5;

@@ -156,16 +156,12 @@ __device__ __forceinline__ void planes_store4(char* Ps, int k, int c, const floa
 #ifndef BF_BUFFER_LOADS
 #define BF_BUFFER_LOADS 1
 #endif
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 template <int PM>
 __device__ __forceinline__ void bf_ldb(const s16x8* __restrict__ Wb, int s, s16x8 (&b)[Split<PM>::NPL][2]) {
   const int lane = lane_id(), r = lane & 31, h = lane >> 5;
 #if BF_BUFFER_LOADS
   // (the member's plane block: NPL planes of 128 KB; wave-uniform base -> scalar registers)
-  const unsigned long long wb = (unsigned long long)Wb;
-  const void* base = (const void*)(((unsigned long long)__builtin_amdgcn_readfirstlane((int)(wb >> 32)) << 32) |
-                                   (unsigned int)__builtin_amdgcn_readfirstlane((int)wb));
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)(Split<PM>::NPL * BF_PLANE * 16), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(Wb, (unsigned)(Split<PM>::NPL * BF_PLANE * 16));
   const int voff = (h * HID + 64 * wave_col() + r) * 16;
 #pragma unroll
   for (int p = 0; p < Split<PM>::NPL; ++p)
