@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace mobody {
 
 constexpr int BM = 64;        // rows per workgroup tile
@@ -58,7 +60,7 @@ __device__ __forceinline__ float activate(float x) {
 }
 
 // --------------------------------------------------------------------------------------------
-// wide GEMM:  acc[mt][nt] (+)= X[64 x Kp] (LDS) * W[Kp x 256] (global, row major, ld = 256)
+// wide GEMM:  acc[mt][nt] = X[64 x Kp] (LDS) * W[Kp x 256] (global, row major, ld = 256)   (acc is written, not accumulated onto)
 // Kp multiple of 8.  Columns of this wave: 64*w + 32*nt + (lane&31).
 // --------------------------------------------------------------------------------------------
 template <int MT>
@@ -83,6 +85,9 @@ __host__ __device__ inline long long wide_idx(int k, int n) { return ((long long
 // ~0.9 us (~2000 cycles): throughput per wave = bytes in flight / latency, so 4 chunks (2 KB per wave) are
 // kept in flight.  (With 2 chunks of 4-byte loads the 640-workgroup twin-Q forward ran at 35 % MFMA busy.)
 constexpr int WIDE_RING = 5;
+#ifndef GEMM_PEEL
+#define GEMM_PEEL 1              // 0: accumulate onto the caller's zero-filled registers (A/B aid)
+#endif
 template <int R>
 struct WideRingT { f32x4 r[R][2]; };
 using WideRing = WideRingT<WIDE_RING>;
@@ -130,7 +135,12 @@ __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const fl
   const int kh = Kp >> 1;                       // K range of this lane half, multiple of 4
   const int nch = kh >> 2;                      // chunks of four k-steps
   const float* xa = Xs + (32 * MT * wave_rg() + i) * LDX + h * kh;
-  auto mma = [&](int c, f32x4 (&b)[2]) {
+  // FIRST (chunk 0): the first MFMA of each accumulator takes a literal zero C operand -- acc is WRITTEN by this GEMM, a
+  // caller's wide_zero is dead code (the chunk loop is a runtime loop: the compiler cannot fold the zero fill itself, and it
+  // costs 32 * MT v_mov per GEMM and wave in kernels whose vector ALU is a third of their busy time)
+  auto mma = [&](auto first_c, int c, f32x4 (&b)[2]) {
+    constexpr bool FIRST = GEMM_PEEL && decltype(first_c)::value;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x4 av[MT];
 #pragma unroll
     for (int x = 0; x < MT; ++x) av[x] = *reinterpret_cast<const f32x4*>(xa + 32 * x * LDX + 4 * c);
@@ -139,8 +149,8 @@ __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const fl
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int x = 0; x < MT; ++x) {
-        acc[x][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][u], b[0][u], acc[x][0], 0, 0, 0);
-        acc[x][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][u], b[1][u], acc[x][1], 0, 0, 0);
+        acc[x][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][u], b[0][u], (FIRST && u == 0) ? zero : acc[x][0], 0, 0, 0);
+        acc[x][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x][u], b[1][u], (FIRST && u == 0) ? zero : acc[x][1], 0, 0, 0);
       }
     __builtin_amdgcn_s_setprio(0);
   };
@@ -149,16 +159,21 @@ __device__ __forceinline__ void wide_gemm(const float* __restrict__ Xs, const fl
   // vmcnt bookkeeping merges the two paths and waits for the loads it has just issued (seen in the ISA of the K = 24
   // layer: load, load, vmcnt(1), mfma -- one L2 round trip per chunk, 7 us for a layer with 0.6 us of MFMA work).
   const bool known = __builtin_constant_p(Kp);
-  for (int c0 = 0; c0 < nch; c0 += R) {
+  // chunk 0 (every K has one), then chunks 1 .. nch - 1: c0 == 1 (mod R), so the ring slot of chunk c0 + j is (1 + j) % R
+  if (!known || R - 1 < nch) wide_ldb(W, Kp, min(R - 1, nch - 1), ring.r[(R - 1) % R]);
+  __builtin_amdgcn_sched_barrier(0);
+  mma(std::true_type{}, 0, ring.r[0]);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int c0 = 1; c0 < nch; c0 += R) {
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const int c = c0 + j;
-      if (!known || c + R - 1 < nch) wide_ldb(W, Kp, min(c + R - 1, nch - 1), ring.r[(j + R - 1) % R]);
+      if (!known || c + R - 1 < nch) wide_ldb(W, Kp, min(c + R - 1, nch - 1), ring.r[(1 + j + R - 1) % R]);
       // Pin the issue order: without this fence hipcc sinks each prefetch load down to its first use (it trades
       // the ring's registers for occupancy), which collapses the 4-chunk prefetch distance to ~1 chunk and puts
       // an L2 round trip in front of every chunk's MFMAs (seen in the ISA: load ... vmcnt(1) ... mfma of it).
       __builtin_amdgcn_sched_barrier(0);
-      if (c < nch) mma(c, ring.r[j]);
+      if (c < nch) mma(std::false_type{}, c, ring.r[(1 + j) % R]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }

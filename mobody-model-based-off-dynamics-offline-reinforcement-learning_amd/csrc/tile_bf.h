@@ -25,6 +25,9 @@
 // "A/B operand lane maps"): lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8h + j] and B[k = 8h + j][col r],
 // j = 0..7; C/D as the fp32 form.
 #pragma once
+#include <type_traits>
+#include <utility>
+
 #include "tile.h"
 
 namespace mobody {
@@ -47,6 +50,12 @@ struct Split {
   static constexpr int RING = SPLIT_RING;        // k16 steps of weight fragments in flight
 };
 constexpr int split_planes(int pm) { return pm == 4 ? 2 : pm; }
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): an unrolled loop whose index is a constant expression
+template <int... J, class F>
+__device__ __forceinline__ void static_seq_impl(std::integer_sequence<int, J...>, F&& f) { (f(std::integral_constant<int, J>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_seq(F&& f) { static_seq_impl(std::make_integer_sequence<int, N>{}, f); }
 
 template <int PM>
 struct BfRing { s16x8 r[Split<PM>::RING][Split<PM>::NPL][2]; };
@@ -183,7 +192,8 @@ __device__ __forceinline__ void bf_prefetch(const s16x8* __restrict__ Wb, BfRing
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// acc[mt][nt] += X (planes in LDS, TB rows per tile, K = 256) * W (planes in global).  `ring` holds bf_prefetch.
+// acc[mt][nt] = X (planes in LDS, TB rows per tile, K = 256) * W (planes in global): acc is WRITTEN, its previous contents are
+// not read (a caller's wide_zero is dead code).  `ring` holds bf_prefetch.
 template <int MT, int PM, int TB>
 __device__ __forceinline__ void bf_gemm(const char* __restrict__ Ps, const s16x8* __restrict__ Wb, f32x16 (&acc)[MT][2],
                                         BfRing<PM>& ring) {
@@ -198,38 +208,50 @@ __device__ __forceinline__ void bf_gemm(const char* __restrict__ Ps, const s16x8
   for (int m = 0; m < MT; ++m)
 #pragma unroll
     for (int j = 0; j < 2; ++j) base[m][j] = plane_off<TB>(8 * h + 4 * j + q, 8 * (MT * wave_rg() + m) + 4 * (g & 1) + pp);
-  for (int s0 = 0; s0 < 16; s0 += R) {
+  // one k-step: weight fragments of step s + R - 1 requested into slot (SL + R - 1) % R, A fragments read, the NPL (NPL + 1) / 2
+  // products of every accumulator issued smallest terms first.  FIRST (step 0): the first product of each accumulator takes a
+  // literal zero as its C operand -- the accumulators are never zero-initialised (32 v_mov per GEMM and wave otherwise: the
+  // loop is a runtime loop, so the compiler cannot fold the caller's zero fill into the first MFMA itself).
+  auto step = [&](auto first_c, int s, auto slot_c) {
+    constexpr bool FIRST = GEMM_PEEL && decltype(first_c)::value;
+    constexpr int SL = decltype(slot_c)::value;
+    if (s + R - 1 < 16) bf_ldb<PM>(Wb, s + R - 1, ring.r[(SL + R - 1) % R]);
+    __builtin_amdgcn_sched_barrier(0);
+    s16x8 a[NPL][MT];
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-      const int s = s0 + j;
-      if (s < 16) {
-        if (s + R - 1 < 16) bf_ldb<PM>(Wb, s + R - 1, ring.r[(j + R - 1) % R]);
-        __builtin_amdgcn_sched_barrier(0);
-        s16x8 a[NPL][MT];
+    for (int p = 0; p < NPL; ++p)
 #pragma unroll
-        for (int p = 0; p < NPL; ++p)
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const char* src = Ps + p * plane_bytes<TB>() + s * (16 * TB * 2);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(src + base[m][0]));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(src + base[m][1]));
-            a[p][m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          }
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int n = 0; n < 2; ++n) {
-            // smallest terms first
-#pragma unroll
-            for (int d = NPL - 1; d >= 0; --d)
-#pragma unroll
-              for (int i = 0; i <= d; ++i) acc[m][n] = split_mfma<PM>(a[i][m], ring.r[j][d - i][n], acc[m][n]);
-          }
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int m = 0; m < MT; ++m) {
+        const char* src = Ps + p * plane_bytes<TB>() + s * (16 * TB * 2);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(src + base[m][0]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(src + base[m][1]));
+        a[p][m] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       }
-    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        bool fresh = FIRST;
+        // smallest terms first
+#pragma unroll
+        for (int d = NPL - 1; d >= 0; --d)
+#pragma unroll
+          for (int i = 0; i <= d; ++i) {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[m][n] = split_mfma<PM>(a[i][m], ring.r[SL][d - i][n], fresh ? zero : acc[m][n]);
+            fresh = false;
+          }
+      }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  step(std::true_type{}, 0, std::integral_constant<int, 0>{});
+  for (int s0 = 1; s0 < 16; s0 += R) {               // steps 1 .. 15: s0 == 1 (mod R), so the ring slot of step s0 + j is (1 + j) % R
+    static_seq<R>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (s0 + j < 16) step(std::false_type{}, s0 + j, std::integral_constant<int, (1 + j) % R>{});
+    });
   }
 }
 
