@@ -80,11 +80,13 @@ __device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, 
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const int col = 64 * wave_col() + 32 * nt + i;
+        // (whole-vector arithmetic: the compiler emits v_pk_mul_f32, two elements per instruction; element loops stay scalar)
+        const f32x16 ys = Split<PM>::F16 ? acc[mt][nt] * sc : acc[mt][nt];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float y4[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) y4[j] = Split<PM>::F16 ? acc[mt][nt][4 * g + j] * sc : acc[mt][nt][4 * g + j];
+          for (int j = 0; j < 4; ++j) y4[j] = ys[4 * g + j];
           planes_store4<PM, TB>(Ps, col, 8 * (MT * wave_rg() + mt) + 2 * g + h, y4, gbase, gs.plane_stride);
         }
       }
@@ -132,13 +134,15 @@ __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* 
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x16 z = acc[mt][nt] + (nt ? bias1 : bias0);          // v_pk_add_f32
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float y = activate<ACT>(acc[mt][nt][r] + (nt ? bias1 : bias0));
+          const float y = activate<ACT>(z[r]);
           acc[mt][nt][r] = y;
           if constexpr (Split<PM>::F16) mx = fmaxf(mx, fabsf(y));
         }
+      }
   }
   // the global plane copy feeds a contraction over ROWS: rows past the end of the batch must be zero there
   // (wave uniform and only on the ragged last tile; their activations are act(bias), harmless for the tile maximum)
@@ -195,12 +199,14 @@ __device__ __forceinline__ void bf_layer(float* Xs, const char* Ps, int e_in, co
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < 2; ++nt) {
+        const float bias = nt ? bias1 : bias0;
+        const f32x16 bv = {bias, bias, bias, bias, bias, bias, bias, bias, bias, bias, bias, bias, bias, bias, bias, bias};
+        const f32x16 iv = {inv, inv, inv, inv, inv, inv, inv, inv, inv, inv, inv, inv, inv, inv, inv, inv};
+        const f32x16 z = Split<PM>::F16 ? __builtin_elementwise_fma(acc[mt][nt], iv, bv) : acc[mt][nt] + bias;   // v_pk_fma_f32 / v_pk_add_f32
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float bias = nt ? bias1 : bias0;
-          acc[mt][nt][r] = activate<ACT>(Split<PM>::F16 ? fmaf(acc[mt][nt][r], inv, bias) : acc[mt][nt][r] + bias);
-        }
+        for (int r = 0; r < 16; ++r) acc[mt][nt][r] = activate<ACT>(z[r]);
+      }
   }
   lds_barrier();                                   // every wave has read the planes
   wide_foreach<MT>(acc, [&](int row, int col, float y) { Xs[row * LDX + col] = y; });

@@ -76,6 +76,9 @@ __device__ __forceinline__ float wide_mask_apply(f32x16 (&acc)[MT][2], const Mas
   const auto& hv = pre.v;
   const auto& mw = pre.w;
   float mx = 0.f;
+  f32x16 pa[MT][2];                                  // acc * prescale as whole vectors (v_pk_mul_f32)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) { pa[mt][0] = acc[mt][0] * prescale; pa[mt][1] = acc[mt][1] * prescale; }
   // full tile (wave uniform): no per-element row guard
   auto sweep = [&](auto guarded) {
 #pragma unroll
@@ -86,7 +89,7 @@ __device__ __forceinline__ float wide_mask_apply(f32x16 (&acc)[MT][2], const Mas
         for (int r = 0; r < 16; ++r) {
           const int rb = (r & 3) + 8 * (r >> 2) + 4 * hh;
           const bool valid = !decltype(guarded)::value || 32 * mt + rb < rows_here;
-          const float a = acc[mt][nt][r] * prescale;
+          const float a = pa[mt][nt][r];
           float dz;
           if constexpr (MASK == 2) {
             dz = valid ? a * hv[mt][nt][r] : 0.f;
@@ -121,14 +124,16 @@ __device__ __forceinline__ void wide_store_colsum(f32x16 (&acc)[MT][2], float* X
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < 2; ++nt) {
+        const f32x16 ys = Split<PM>::F16 ? acc[mt][nt] * sc : acc[mt][nt];               // v_pk_mul_f32
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           float y4[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) y4[j] = Split<PM>::F16 ? acc[mt][nt][4 * g + j] * sc : acc[mt][nt][4 * g + j];
+          for (int j = 0; j < 4; ++j) y4[j] = ys[4 * g + j];
           planes_store4<PM, 32 * MT>(reinterpret_cast<char*>(Xs), 64 * w + 32 * nt + i, 8 * mt + 2 * g + hh, y4, gs.base, gs.plane_stride);
         }
+      }
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
