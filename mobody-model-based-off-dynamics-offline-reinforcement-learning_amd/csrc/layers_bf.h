@@ -69,11 +69,13 @@ __device__ __forceinline__ void wide_store_rows(f32x16 (&acc)[MT][2], float* dst
 
 // Write the planes of a wide result held in accumulators (values y, scaled by 2^e in the f16 mode): four consecutive rows
 // of a lane's feature go out as one 8-byte store per plane (and, optionally, one more to the global copy gs).
+// `groups`: 32-row groups of the tile that hold real rows -- the global copy is padded to whole groups of 32 rows, not to whole
+// tiles, so a taller tile's groups past the end of the batch must not be written (they would land in the next plane / member).
 template <int MT, int PM, int TB>
-__device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, int e, const PlaneSave& gs) {
+__device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, int e, const PlaneSave& gs, int groups = 1 << 30) {
   const int lane = lane_id(), i = lane & 31, h = lane >> 5;
   const float sc = Split<PM>::F16 ? exp2i(e) : 1.f;
-  if (gs.base != nullptr && (int)threadIdx.x < TB / 32) gs.e_out[threadIdx.x] = e;      // one exponent per 32 rows
+  if (gs.base != nullptr && (int)threadIdx.x < min(TB / 32, groups)) gs.e_out[threadIdx.x] = e;      // one exponent per 32 rows
   auto sweep = [&](short* gbase) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -87,7 +89,8 @@ __device__ __forceinline__ void planes_from_acc(f32x16 (&acc)[MT][2], char* Ps, 
           float y4[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) y4[j] = ys[4 * g + j];
-          planes_store4<PM, TB>(Ps, col, 8 * (MT * wave_rg() + mt) + 2 * g + h, y4, gbase, gs.plane_stride);
+          planes_store4<PM, TB>(Ps, col, 8 * (MT * wave_rg() + mt) + 2 * g + h, y4, (MT * wave_rg() + mt) < groups ? gbase : nullptr,
+                                gs.plane_stride);
         }
       }
   };
@@ -159,7 +162,7 @@ __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* 
   lds_barrier();                                   // every wave has read the old image (and posted its maximum)
   int e = 0;
   if constexpr (Split<PM>::F16) e = f16_scale_exp(f16_tile_max_get(scr));
-  planes_from_acc<MT, PM, TB>(acc, Ps, e, gs);
+  planes_from_acc<MT, PM, TB>(acc, Ps, e, gs, (min(rows_here, TB) + 31) / 32);
   if (gsave != nullptr) wide_store_rows<MT>(acc, gsave, full, rows_here);
   TR(7);
   if (mask != nullptr) relu_mask_words<MT>(acc, mask, mask_groups);

@@ -17,15 +17,21 @@
 #ifndef FWD_LOAD2
 #define FWD_LOAD2 1            // 0: one tile_load per input source (A/B aid)
 #endif
+#ifndef FWD_BF_MT
+#define FWD_BF_MT 1            // 1: 32-row forward tiles (product); 2: 64-row tiles, 0: 64-row from FWD_MT2_MIN_TILES on (experiments)
+#endif
+#ifndef FWD_MT2_MIN_TILES
+#define FWD_MT2_MIN_TILES 1536 // 32-row tiles per launch (6 per CU) from which the 64-row tile is used
+#endif
 #ifndef FWD_F16_WAVES
 #define FWD_F16_WAVES 4
 #endif
 namespace mobody {
 
 // DS: training forward of a Swish net -- save_d1 / save_d2 receive the derivatives next to h1 (planes or rows) / h2
-template <int ACT, int PM, int RG, int NT, bool DS = false>
+template <int ACT, int PM, int RG, int NT, bool DS = false, int MT = 1>
 __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, float* Xs) {
-  constexpr int MT = 1, TB = 32 * RG;
+  constexpr int TB = 32 * MT * RG;
   char* Ps = reinterpret_cast<char*>(Xs);
   float* scr = reinterpret_cast<float*>(Ps + split_scr_offset<PM, TB>());
   const long long row0 = (long long)blockIdx.x * TB;
@@ -106,27 +112,27 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
 }
 
 // one or two independent networks per launch (blockIdx.y < members_a -> net a), as k_mlp3_fwd2
-template <int ACT, int PM, int RG, int NT, bool DS = false>
-__global__ __launch_bounds__(NTHREADS * RG, (PM == 4 && RG == 1 && !DS) ? FWD_F16_WAVES : 2) void k_mlp3_fwd_bf(Mlp3FwdArgs a, Mlp3FwdArgs b, int members_a) {
+template <int ACT, int PM, int RG, int NT, bool DS = false, int MT = 1>
+__global__ __launch_bounds__(NTHREADS * RG, (PM == 4 && RG == 1 && !DS && MT == 1) ? FWD_F16_WAVES : 2) void k_mlp3_fwd_bf(Mlp3FwdArgs a, Mlp3FwdArgs b, int members_a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   const bool second = (int)blockIdx.y >= members_a;
   const Mlp3FwdArgs s = second ? b : a;
-  if ((long long)blockIdx.x * (32 * RG) >= s.rows) return;
-  mlp3_fwd_bf_tile<ACT, PM, RG, NT, DS>(s, second ? (int)blockIdx.y - members_a : (int)blockIdx.y, Xs);
+  if ((long long)blockIdx.x * (32 * MT * RG) >= s.rows) return;
+  mlp3_fwd_bf_tile<ACT, PM, RG, NT, DS, MT>(s, second ? (int)blockIdx.y - members_a : (int)blockIdx.y, Xs);
 }
 
-template <int ACT, int PM, int RG, int NT, bool DS = false>
+template <int ACT, int PM, int RG, int NT, bool DS = false, int MT = 1>
 static int launch_bf_t(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, hipStream_t st) {
-  constexpr size_t lds = split_lds_bytes<PM, 32 * RG>();
+  constexpr size_t lds = split_lds_bytes<PM, 32 * MT * RG>();
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_mlp3_fwd_bf<ACT, PM, RG, NT, DS>, 160 * 1024);
+    int rc = allow_big_lds(k_mlp3_fwd_bf<ACT, PM, RG, NT, DS, MT>, 160 * 1024);
     if (rc) return rc;
     once = true;
   }
   const long long rows = a.rows > b.rows ? a.rows : b.rows;
   ProfScope prof(PROF_MLP_FWD, st);
-  hipLaunchKernelGGL((k_mlp3_fwd_bf<ACT, PM, RG, NT, DS>), dim3((unsigned)cdiv(rows, 32 * RG), (unsigned)(members_a + members_b)),
+  hipLaunchKernelGGL((k_mlp3_fwd_bf<ACT, PM, RG, NT, DS, MT>), dim3((unsigned)cdiv(rows, 32 * MT * RG), (unsigned)(members_a + members_b)),
                      dim3(NTHREADS * RG), lds, st, a, b, members_a);
   MB_LAUNCH_OK("k_mlp3_fwd_bf");
   return 0;
@@ -154,6 +160,17 @@ int launch_mlp3_fwd_bf(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b
     const int np3 = x.Np3;
     return np3 == 16 ? launch_bf_t<ACT_SWISH, 4, 1, 1, true>(x, mx, y, 0, st) : np3 == 32 ? launch_bf_t<ACT_SWISH, 4, 1, 2, true>(x, mx, y, 0, st)
                                                                               : launch_bf_t<ACT_SWISH, 4, 1, 0, true>(x, mx, y, 0, st);
+  }
+  // Tile height of the f16x2 ReLU launches.  64-row tiles (MT = 2: each weight fragment feeds two row tiles, half the L2 -> CU
+  // weight stream, two workgroups per CU) win only on a bare twin-Q forward of several generations (40 960 rows: 48.3 us
+  // against 50.8; 10 240 rows: 19.8 against 17.4) and lose in the train step, whose forwards also save activations: c3 forward
+  // 302 against 297 us per step, c4 280 against 258.  The product uses 32-row tiles; FWD_BF_MT = 2 / 0 builds the experiment.
+  if (act == ACT_RELU && prec == 4) {
+    const int np3 = x.rows > 0 ? x.Np3 : y.Np3;
+    const long long tiles32 = cdiv(x.rows > 0 ? x.rows : 0, 32) * mx + cdiv(y.rows > 0 ? y.rows : 0, 32) * my;
+    const bool tall = FWD_BF_MT == 2 || (FWD_BF_MT == 0 && tiles32 >= FWD_MT2_MIN_TILES);
+    if (tall && np3 == 16) return launch_bf_t<ACT_RELU, 4, 1, 1, false, 2>(x, mx, y, my, st);
+    if (tall && np3 == 32) return launch_bf_t<ACT_RELU, 4, 1, 2, false, 2>(x, mx, y, my, st);
   }
 #define BF_CASE(ACT, PM) (rg == 1 ? launch_bf_nt<ACT, PM, 1>(x, mx, y, my, st) : launch_bf_nt<ACT, PM, 2>(x, mx, y, my, st))
   if (act == ACT_SWISH) return prec == 1 ? BF_CASE(ACT_SWISH, 1) : prec == 2 ? BF_CASE(ACT_SWISH, 2) : prec == 3 ? BF_CASE(ACT_SWISH, 3) : BF_CASE(ACT_SWISH, 4);
