@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MOBODY_ABI_VERSION 5
+#define MOBODY_ABI_VERSION 6
 #define MOBODY_E_ARG (-1)      /* bad argument (dims, null pointer, unsupported size) */
 #define MOBODY_E_LAUNCH (-2)   /* hipLaunch / runtime error */
 #define MOBODY_E_UNSUPPORTED (-3)
@@ -407,7 +407,11 @@ int mobody_pretrain_gather(const float* state, const float* action, const float*
 int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, int use_trg, float encoder_loss_coef,
                           const float* blob, const float* blob_T, const float* xenc, const float* act, const float* rew,
                           const float* noise6, const float* noise7, uint32_t seed, uint32_t call, float* grad,
-                          float* loss_out, float* workspace, int precision, void* stream);
+                          float* loss_out, float* workspace, int precision, float transition_coef, float reward_coef,
+                          void* stream);
+/* transition_coef / reward_coef: weights of transition_loss and reward_loss in this call's loss (1, 1 = learn()).
+ * inverse_sep_reward_loss = 1 runs learn() with reward_coef 0 and learn_sep_reward (:482-519) with encoder_loss_coef 0,
+ * transition_coef 0, reward_coef 1. */
 
 /* Single-GPU form of mobody_pretrain_grads + mobody_pretrain_adam: every gradient reduction applies the Adam step of the
  * elements it has just reduced (no gradient blob, four launches fewer).  t_dev (nullable): DEVICE int64[2] = {t_main,
@@ -423,7 +427,10 @@ int mobody_pretrain_update(int S, int A, int64_t b, int use_trg, float encoder_l
  * action encoder of this step's domain t_za; the other action encoder is skipped (its .grad is None in the reference,
  * so its Adam state does not advance). */
 int mobody_pretrain_adam(int S, int A, int use_trg, float* blob, float* blob_T, const float* grad, float* m, float* v,
-                         int64_t t_main, int64_t t_za, float lr, float grad_scale, int precision, void* stream);
+                         int64_t t_main, int64_t t_za, float lr, float grad_scale, int precision, int net_mask, int64_t t_rw,
+                         void* stream);
+/* net_mask: bit 0 state encoder, bit 1 decoder, bit 2 reward head -- a net without a gradient in this step is skipped and
+ * keeps its step count (7 and t_rw = t_main: every net, one count -- learn()); the reward head steps with its own t_rw. */
 
 /* Adam step of ONE action encoder only (blob layout, its own 1-based step count): the second encoder of a learn_src_trg step
  * (config train_together = 1, :521-590 -- the summed source + target loss moves both, mobody_pretrain_adam steps one). */

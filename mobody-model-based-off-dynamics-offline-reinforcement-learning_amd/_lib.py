@@ -122,8 +122,8 @@ PROTOTYPES = {
     "mobody_pretrain_update": (C.c_int, [C.c_int, C.c_int, i64, C.c_int, f32, vp, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp,
                                          vp, i64, i64, vp, f32, vp, vp, vp, C.c_int, vp]),
     "mobody_pretrain_grads": (C.c_int, [C.c_int, C.c_int, i64, i64, C.c_int, f32, vp, vp, vp, vp, vp, vp, vp, u32, u32,
-                                        vp, vp, vp, C.c_int, vp]),
-    "mobody_pretrain_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, i64, i64, f32, f32, C.c_int, vp]),
+                                        vp, vp, vp, C.c_int, f32, f32, vp]),
+    "mobody_pretrain_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, i64, i64, f32, f32, C.c_int, C.c_int, i64, vp]),
     "mobody_pretrain_za_adam": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, i64, f32, f32, vp]),
     "mobody_dyn_validate_workspace": (i64, [C.c_int, C.c_int, i64]),
     "mobody_dyn_validate": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, i64, C.c_int, vp, vp, vp]),
@@ -148,7 +148,7 @@ def load():
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.mobody_abi_version() != 5:
+    if lib.mobody_abi_version() != 6:
         raise ImportError("libmobody_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -130,15 +130,19 @@ class MOBODYEnsembleDynamics(object):
     # ------------------------------------------------------------------ pre-training (mobody_dynamics.py:594-653,731-978,1113-1156)
     def _check_pretrain_config(self):
         cfg = self.config
-        if cfg.get("inverse_sep_reward_loss") or cfg.get("latent_reward"):
-            raise NotImplementedError("inverse_sep_reward_loss / latent_reward are ablations outside the accelerated pre-training "
-                                      "path (reference defaults are 0; with latent_reward = 1 the reference's own learn() raises "
-                                      "TypeError: reward_loss_with_latent calls encode_trg_action(action) without the state, "
-                                      "mobody_dynamics.py:409 against mobody_module.py:258)")
-        if cfg.get("train_together") and self._world()[0] > 1:
-            raise NotImplementedError("train_together = 1 is supported on one GPU (learn_src_trg is not sharded)")
+        if cfg.get("latent_reward"):
+            raise NotImplementedError("latent_reward = 1 is outside the accelerated pre-training path (reference default 0; the "
+                                      "reference's own learn() raises TypeError with it: reward_loss_with_latent calls "
+                                      "encode_trg_action(action) without the state, mobody_dynamics.py:409 against mobody_module.py:258)")
+        if (cfg.get("train_together") or cfg.get("inverse_sep_reward_loss")) and self._world()[0] > 1:
+            raise NotImplementedError("train_together / inverse_sep_reward_loss are supported on one GPU (their joint steps are not sharded)")
+        if cfg.get("train_together") and cfg.get("inverse_sep_reward_loss"):
+            raise NotImplementedError("train_together together with inverse_sep_reward_loss is not mirrored")
         if cfg.get("train_with_src_threshold", 1) != 1:
             raise NotImplementedError("train_with_src_threshold != 1 (data_augmentation) is outside the accelerated path")
+
+    def _sep(self):
+        return bool(self.config.get("inverse_sep_reward_loss"))
 
     def _enc_coef(self):
         """Weight of encoder_loss in the step's loss.  config['no_vae'] = 1 (mobody_dynamics.py:616-635): the reference neither
@@ -181,15 +185,18 @@ class MOBODYEnsembleDynamics(object):
             ops.pretrain_grads(S, A, b, use_trg, self._enc_coef(), st["blob"], st["blob_T"], xenc, act, rew, st["grad"],
                                self._pre_loss, ws, noise6=n6, noise7=n7,
                                seed=(self.seed + 77 + dp.rank_salt()) & 0xFFFFFFFF, call=self._train_calls, b_global=b_global,
-                               precision=self.train_precision)
+                               precision=self.train_precision, reward_coef=0.0 if self._sep() else 1.0)
         else:                                             # data parallel: this rank has no row of a ragged last batch
             st["grad"].zero_(); self._pre_loss.zero_()
         if world > 1:
             torch.distributed.all_reduce(st["grad"])      # one 6.5 MB message per step
             torch.distributed.all_reduce(self._pre_loss)
         st["t_main"] += 1; st["t_za"][bool(use_trg)] += 1
+        # inverse_sep_reward_loss: learn() leaves reward_loss out (:637-641) -- the reward head has no gradient, Adam skips it and
+        # its step count (st["t_rw"], advanced by learn_sep_reward only) stays
         ops.pretrain_adam(S, A, use_trg, st["blob"], st["blob_T"], st["grad"], st["m"], st["v"], st["t_main"],
-                          st["t_za"][bool(use_trg)], self._lr(), precision=self.train_precision)
+                          st["t_za"][bool(use_trg)], self._lr(), precision=self.train_precision,
+                          net_mask=3 if self._sep() else 7, t_rw=None)
         m.mark_trained()
         return self._pre_loss
 
@@ -294,6 +301,73 @@ class MOBODYEnsembleDynamics(object):
         lo, hi = rows * rank // world, rows * (rank + 1) // world
         return start + lo, hi - lo
 
+    # ---- config['inverse_sep_reward_loss'] = 1: learn_sep_reward, mobody_dynamics.py:482-519 -----------------------------------
+    def _learn_sep_reward_batch(self, src, trg):
+        """One optimizer step on reward_loss(source batch) + reward_loss(target batch) only; src / trg = (xenc, act, rew, b).
+        Two gradient calls with encoder and transition weights 0, the blobs added, one Adam step: the reward head steps with its
+        own count (learn() skipped it), everything the fake next state reaches -- encoder, decoder, both action encoders --
+        with theirs.  Returns the device scalar of the total loss."""
+        m = self.model
+        st = m.train_state(self.train_precision)
+        if "grad2" not in st:
+            st["grad2"] = torch.zeros_like(st["grad"])
+            self._pre_loss2 = torch.zeros_like(self._pre_loss)
+        st.setdefault("t_rw", 0)
+        S, A = m.obs_dim, m.action_dim
+        st["grad"].zero_(); st["grad2"].zero_()
+        for (xenc, act, rew, b), d, grad, out in ((src, False, st["grad"], self._pre_loss), (trg, True, st["grad2"], self._pre_loss2)):
+            self._train_calls += 1
+            n6 = n7 = None
+            if self.train_noise_fn is not None:
+                n6, n7 = self.train_noise_fn(b)
+            ops.pretrain_grads(S, A, b, d, 0.0, st["blob"], st["blob_T"], xenc, act, rew, grad, out, self._ws_for(b), noise6=n6,
+                               noise7=n7, seed=(self.seed + 77) & 0xFFFFFFFF, call=self._train_calls,
+                               precision=self.train_precision, transition_coef=0.0, reward_coef=1.0)
+        st["grad"] += st["grad2"]
+        st["t_main"] += 1; st["t_rw"] += 1; st["t_za"][False] += 1; st["t_za"][True] += 1
+        ops.pretrain_adam(S, A, True, st["blob"], st["blob_T"], st["grad"], st["m"], st["v"], st["t_main"], st["t_za"][True],
+                          self._lr(), precision=self.train_precision, net_mask=7, t_rw=st["t_rw"])
+        ops.pretrain_za_adam(S, A, False, st["blob"], st["grad"], st["m"], st["v"], st["t_za"][False], self._lr())
+        m.mark_trained()
+        return self._pre_loss[0] + self._pre_loss2[0]
+
+    def _learn_sep_reward_loop(self, n_trg, batch_size, batch):
+        self.model.training = True
+        acc = torch.zeros((), dtype=torch.float32, device=self.model.device)
+        n_batch = int(np.ceil(n_trg / batch_size))
+        for k in range(n_batch):
+            self.total_steps = getattr(self, "total_steps", 0) + 1
+            acc += self._learn_sep_reward_batch(*batch(k))
+        return float(acc / max(n_batch, 1))
+
+    def learn_sep_reward(self, src_train_obss, src_train_actions, src_train_next_obss, src_train_rewards, trg_train_obss,
+                         trg_train_actions, trg_train_next_obss, trg_train_rewards, batch_size):
+        """mobody_dynamics.py:482-519 on per-member rows `[7, n, .]` of both domains -> mean total reward loss."""
+        self._check_pretrain_config()
+        dev = self.model.device
+        f = lambda x: torch.as_tensor(x, dtype=torch.float32).to(dev)
+        S_ = [f(src_train_obss), f(src_train_actions), f(src_train_next_obss), f(src_train_rewards).reshape(7, -1)]
+        T_ = [f(trg_train_obss), f(trg_train_actions), f(trg_train_next_obss), f(trg_train_rewards).reshape(7, -1)]
+
+        def rows(D, k):
+            sl = slice(k * batch_size, (k + 1) * batch_size)
+            s = D[0][:, sl]
+            return torch.cat([s, D[2][:, sl]], 1).contiguous(), D[1][:, sl].contiguous(), D[3][:, sl].contiguous(), s.shape[1]
+
+        return self._learn_sep_reward_loop(T_[0].shape[1], batch_size, lambda k: (rows(S_, k), rows(T_, k)))
+
+    def _learn_sep_reward_indexed(self, src, src_idx, trg, trg_idx, batch_size):
+        n_s, n_t = src_idx.shape[1], trg_idx.shape[1]
+
+        def gather(data, idx, n, k):
+            lo = k * batch_size
+            b = min(batch_size, n - lo)
+            assert b > 0, "learn_sep_reward walks the source rows in step with the target batches: not enough source rows"
+            xenc, act, rew = ops.pretrain_gather(data[0], data[1], data[2], data[3], idx, lo, b)
+            return xenc, act, rew, b
+
+        return self._learn_sep_reward_loop(n_t, batch_size, lambda k: (gather(src, src_idx, n_s, k), gather(trg, trg_idx, n_t, k)))
+
     # ---- config['train_together'] = 1: learn_src_trg, mobody_dynamics.py:521-590 ------------------------------------------
     def _learn_src_trg_batch(self, src, trg):
         """One optimizer step on loss(source batch) + loss(target batch); src / trg = (xenc, act, rew, b).  The target
@@ -396,13 +470,13 @@ class MOBODYEnsembleDynamics(object):
             if b == 0:
                 return self._learn_batch(use_trg, None, None, None, 0, rows, lo - start)
             xenc, act, rew = ops.pretrain_gather(data[0], data[1], data[2], data[3], idx, lo, b, out=self._gather_bufs(b))
-            if world == 1:
+            if world == 1 and not self._sep():
                 return self._learn_batch_fused(use_trg, xenc, act, rew, b, acc)
             return self._learn_batch(use_trg, xenc, act, rew, b, rows, lo - start)
 
         n = idx.shape[1]
         n_full = n // batch_size
-        if world == 1 and self.train_graph and self.train_noise_fn is None and n_full >= 3:
+        if world == 1 and self.train_graph and self.train_noise_fn is None and n_full >= 3 and not self._sep():
             self.model.training = True
             acc = self._learn_graph(use_trg, data, idx, batch_size, n_full).clone()
             n_batch = n_full
@@ -504,6 +578,8 @@ class MOBODYEnsembleDynamics(object):
                 writer.add_scalar("trg_loss/dynamics_train_loss", trg_stats[1], global_step=epoch)
                 writer.add_scalar("trg_loss/dynamics_encoder_loss", trg_stats[2], global_step=epoch)
                 writer.add_scalar("trg_loss/dynamics_holdout_loss", trg_holdout_loss, global_step=epoch)
+            if not together and self._sep():                                                # :935-941 (after the target passes + validation)
+                self._learn_sep_reward_indexed(src_tr, src_idx, trg_tr, trg_idx, batch_size)
             if not together:                                                                # (:943-944 sit inside the else branch)
                 src_idx.copy_(bc(self.shuffle_rows(src_idx).contiguous()))                  # :934-935 (in place: the captured
                 trg_idx.copy_(bc(self.shuffle_rows(trg_idx).contiguous()))                  #  graphs keep reading these tensors)

@@ -116,7 +116,8 @@ struct PreRow {
   int S, A, use_trg, Np3tr;
   long long b;               // rows per member on this rank
   float inv_bg;              // 1 / (rows per member summed over data-parallel ranks)
-  float ce, cr;              // (5 if trg else 1) * encoder_loss_coef ; reward-loss factor 1 (trg) / 0.01 (src)
+  float ce, cr;              // (5 if trg else 1) * encoder_loss_coef ; reward-loss factor 1 (trg) / 0.01 (src), times reward_coef
+  float ct;                  // weight of transition_loss in the step's loss (1; 0 in a reward-only step, learn_sep_reward :482-519)
   const float* xenc;         // [E][2b][S]   s rows, then s' rows
   const float* act;          // [E][b][A]
   const float* rew;          // [E][b]
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void k_pre_trans_loss(PreRow a, PreLossOff lo)
   const int e = (int)(ic / (b * S));
   const long long row = (ic - (long long)e * b * S) / S;
   const int d = (int)(ic - ((long long)e * b + row) * S);
-  const float c_rec = a.ce * 100.f * 2.f * a.inv_bg / (float)S, c_tr = 2.f * a.inv_bg / (float)S;
+  const float c_rec = a.ce * 100.f * 2.f * a.inv_bg / (float)S, c_tr = a.ct * 2.f * a.inv_bg / (float)S;
   float m6[NENS], avg = 0.f;
 #pragma unroll
   for (int k = 0; k < NENS; ++k) { m6[k] = a.tr_out[((long long)k * 4 * b + 3 * b + row) * S + d]; avg += m6[k]; }
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256) void k_pre_za_reduce(const float* zap, int nch
 // out[5] = (loss, transition_loss, encoder_loss, recon_loss, kl_loss) as learn() reports them (:630-650); local shares
 // of the global means when data parallel.
 __global__ __launch_bounds__(256) void k_pre_loss_final(const float* lossp, PreLossOff lo, float inv_bg, int S, float ce,
-                                                        float cr, float* out, float* acc) {
+                                                        float cr, float ct, float* out, float* acc) {
   __shared__ float sm[5][4];
   float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};                // latent, kl, recon, trans, reward
   for (int k = threadIdx.x; k < lo.n_lat; k += 256) { v[0] += lossp[lo.lat + 2 * k]; v[1] += lossp[lo.lat + 2 * k + 1]; }
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) void k_pre_loss_final(const float* lossp, PreL
     const float lat = t[0] * inv_bg / LATENT, kl = 0.05f * t[1] * inv_bg / LATENT;
     const float recon = t[2] * inv_bg / S, trans = t[3] * inv_bg / S, rl = cr * t[4] * inv_bg;
     const float enc = 100.f * recon + kl + lat;
-    out[0] = trans + ce * enc + rl; out[1] = trans; out[2] = enc; out[3] = recon; out[4] = kl;
+    out[0] = ct * trans + ce * enc + rl; out[1] = trans; out[2] = enc; out[3] = recon; out[4] = kl;
     if (acc != nullptr) { acc[0] += out[0]; acc[1] += trans; acc[2] += enc; acc[3] += recon; acc[4] += kl; }   // learn()'s running sums (:630-650)
   }
 }
@@ -770,7 +771,7 @@ static int pretrain_impl(int S, int A, int64_t b, int64_t b_global, int use_trg,
                          const float* blob, const float* blob_T, const float* xenc, const float* act,
                          const float* rew, const float* noise6, const float* noise7, uint32_t seed, uint32_t call,
                          const int64_t* call_dev, float* grad, const PreOpt& opt, float* loss_out, float* loss_acc,
-                         float* workspace, int precision, void* stream) {
+                         float* workspace, int precision, void* stream, float transition_coef = 1.f, float reward_coef = 1.f) {
   MobodyPretrainLayout L;
   int rc = mobody_pretrain_layout(S, A, &L);
   if (rc) return rc;
@@ -798,7 +799,7 @@ static int pretrain_impl(int S, int A, int64_t b, int64_t b_global, int use_trg,
   }
   PreRow r{};
   r.S = S; r.A = A; r.use_trg = use_trg; r.Np3tr = L.tr.Np3; r.b = b; r.inv_bg = 1.f / (float)b_global;
-  r.ce = (use_trg ? 5.f : 1.f) * encoder_loss_coef; r.cr = use_trg ? 1.f : 0.01f;
+  r.ce = (use_trg ? 5.f : 1.f) * encoder_loss_coef; r.cr = (use_trg ? 1.f : 0.01f) * reward_coef; r.ct = transition_coef;
   r.xenc = xenc; r.act = act; r.rew = rew; r.noise6 = noise6; r.noise7 = noise7; r.seed = seed; r.call = call;
   r.call_dev = (const long long*)call_dev;
   r.za = blob + (use_trg ? L.off_za_trg : L.off_za_src);
@@ -892,7 +893,7 @@ static int pretrain_impl(int S, int A, int64_t b, int64_t b_global, int use_trg,
     if (hipEventRecord(side->join, st2) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess)
       return fail(MOBODY_E_LAUNCH, "pre-training: join of the side stream failed");
   }
-  hipLaunchKernelGGL(k_pre_loss_final, dim3(1), dim3(256), 0, st, w.lossp, w.lo, r.inv_bg, S, r.ce, r.cr, loss_out, loss_acc);
+  hipLaunchKernelGGL(k_pre_loss_final, dim3(1), dim3(256), 0, st, w.lossp, w.lo, r.inv_bg, S, r.ce, r.cr, r.ct, loss_out, loss_acc);
   MB_LAUNCH_OK("k_pre_loss_final");
   return 0;
 }
@@ -900,10 +901,11 @@ static int pretrain_impl(int S, int A, int64_t b, int64_t b_global, int use_trg,
 extern "C" int mobody_pretrain_grads(int S, int A, int64_t b, int64_t b_global, int use_trg, float encoder_loss_coef,
                                      const float* blob, const float* blob_T, const float* xenc, const float* act,
                                      const float* rew, const float* noise6, const float* noise7, uint32_t seed, uint32_t call,
-                                     float* grad, float* loss_out, float* workspace, int precision, void* stream) {
+                                     float* grad, float* loss_out, float* workspace, int precision, float transition_coef,
+                                     float reward_coef, void* stream) {
   MB_REQUIRE(grad, "mobody_pretrain_grads: grad is null");
   return pretrain_impl(S, A, b, b_global, use_trg, encoder_loss_coef, blob, blob_T, xenc, act, rew, noise6, noise7, seed, call,
-                       nullptr, grad, PreOpt{}, loss_out, nullptr, workspace, precision, stream);
+                       nullptr, grad, PreOpt{}, loss_out, nullptr, workspace, precision, stream, transition_coef, reward_coef);
 }
 
 extern "C" int mobody_pretrain_update(int S, int A, int64_t b, int use_trg, float encoder_loss_coef, float* blob, float* blob_T,
@@ -920,20 +922,21 @@ extern "C" int mobody_pretrain_update(int S, int A, int64_t b, int use_trg, floa
 
 extern "C" int mobody_pretrain_adam(int S, int A, int use_trg, float* blob, float* blob_T, const float* grad, float* m,
                                     float* v, int64_t t_main, int64_t t_za, float lr, float grad_scale, int precision,
-                                    void* stream) {
+                                    int net_mask, int64_t t_rw, void* stream) {
   MobodyPretrainLayout L;
   int rc = mobody_pretrain_layout(S, A, &L);
   if (rc) return rc;
   rc = pre_check_prec(precision, "mobody_pretrain_adam");
   if (rc) return rc;
   MB_REQUIRE(blob && blob_T && grad && m && v, "mobody_pretrain_adam: null pointer");
-  MB_REQUIRE(t_main >= 1 && t_za >= 1, "mobody_pretrain_adam: step counts are 1-based");
+  MB_REQUIRE(t_main >= 1 && t_za >= 1 && (!(net_mask & 4) || t_rw >= 1), "mobody_pretrain_adam: step counts are 1-based");
   hipStream_t st = as_stream(stream);
   const MobodyMlpLayout* nets[3] = {&L.enc, &L.tr, &L.rw};
   const int64_t offs[3] = {L.off_enc, L.off_tr, L.off_rw}, toffs[3] = {L.t_off_enc, L.t_off_tr, L.t_off_rw};
   for (int k = 0; k < 3; ++k) {
-    const AdamTarget a = pre_adam_target(blob + offs[k], blob_T + toffs[k], m + offs[k], v + offs[k], t_main, nullptr, lr, grad_scale,
-                                         precision);
+    if (!((net_mask >> k) & 1)) continue;              // a net whose .grad is None in the reference: Adam skips it, its count stays
+    const AdamTarget a = pre_adam_target(blob + offs[k], blob_T + toffs[k], m + offs[k], v + offs[k], k == 2 ? t_rw : t_main, nullptr, lr,
+                                         grad_scale, precision);
     rc = launch_adam(a, grad + offs[k], *nets[k], st);
     if (rc) return rc;
   }

@@ -428,11 +428,11 @@ def pretrain_gather(state, action, next_state, reward, idx, start, b, out=None, 
 
 
 def pretrain_grads(S, A, b, use_trg, encoder_loss_coef, blob, blob_T, xenc, act, rew, grad, loss_out, ws, noise6=None,
-                   noise7=None, seed=0, call=0, b_global=None, precision=0):
+                   noise7=None, seed=0, call=0, b_global=None, precision=0, transition_coef=1.0, reward_coef=1.0):
     check(load().mobody_pretrain_grads(S, A, b, b if b_global is None else b_global, int(bool(use_trg)),
                                        float(encoder_loss_coef), ptr(blob), ptr(blob_T), ptr(xenc), ptr(act), ptr(rew),
                                        ptr(noise6), ptr(noise7), seed, call, ptr(grad), ptr(loss_out), ptr(ws),
-                                       prec_id(precision), cur_stream()), "mobody_pretrain_grads")
+                                       prec_id(precision), float(transition_coef), float(reward_coef), cur_stream()), "mobody_pretrain_grads")
 
 
 def pretrain_update(S, A, b, use_trg, encoder_loss_coef, blob, blob_T, xenc, act, rew, m, v, t_main, t_za, lr, loss_out, ws,
@@ -443,9 +443,12 @@ def pretrain_update(S, A, b, use_trg, encoder_loss_coef, blob, blob_T, xenc, act
           "mobody_pretrain_update")
 
 
-def pretrain_adam(S, A, use_trg, blob, blob_T, grad, m, v, t_main, t_za, lr, grad_scale=1.0, precision=0):
+def pretrain_adam(S, A, use_trg, blob, blob_T, grad, m, v, t_main, t_za, lr, grad_scale=1.0, precision=0, net_mask=7, t_rw=None):
+    """net_mask: bit 0 state encoder, 1 decoder, 2 reward head (a net without a gradient this step is skipped); t_rw: the reward
+    head's own step count (default: t_main)."""
     check(load().mobody_pretrain_adam(S, A, int(bool(use_trg)), ptr(blob), ptr(blob_T), ptr(grad), ptr(m), ptr(v), t_main,
-                                      t_za, float(lr), float(grad_scale), prec_id(precision), cur_stream()), "mobody_pretrain_adam")
+                                      t_za, float(lr), float(grad_scale), prec_id(precision), int(net_mask),
+                                      t_main if t_rw is None else t_rw, cur_stream()), "mobody_pretrain_adam")
 
 
 def pretrain_za_adam(S, A, use_trg, blob, grad, m, v, t_za, lr, grad_scale=1.0):

@@ -491,7 +491,7 @@ TRAINED_LAYERS = ("zs1", "zs2", "zs3", "za_src1", "za_src2", "za_trg1", "za_trg2
                   "transition3", "reward_model1", "reward_model2", "reward_model3")
 
 
-def dyn_learn_losses(p, obs, act, next_obs, rew, noise, use_trg, encoder_loss_coef=1.0):
+def dyn_learn_losses(p, obs, act, next_obs, rew, noise, use_trg, encoder_loss_coef=1.0, transition_coef=1.0, reward_coef=1.0):
     """The loss of one `learn()` batch, mobody_dynamics.py:594-653 (no_vae=0, latent_reward=0, inverse_sep_reward_loss=0):
 
       encoder_loss (:300-330)   100 * [sum_e mean_{b,d}(dec(z1) - s)^2 + ... (dec(z2) - s')^2]
@@ -530,13 +530,13 @@ def dyn_learn_losses(p, obs, act, next_obs, rew, noise, use_trg, encoder_loss_co
     enc_loss = 100 * recon + kl_loss + (((z3 + za(z3)) - z4) ** 2).mean(dim=(1, 2)).sum()
     z5, _, _ = enc(s, n[4])
     trans = ((dyn_decode_transition(p, z5 + za(z5)) - s2) ** 2).mean(dim=(1, 2)).sum()
-    loss = trans + (5 if use_trg else 1) * encoder_loss_coef * enc_loss
+    loss = transition_coef * trans + (5 if use_trg else 1) * encoder_loss_coef * enc_loss
     z6, _, _ = enc(s, n[5])
     mean6 = dyn_decode_transition(p, z6 + za(z6))
     fake = mean6 + n[6] * torch.std(mean6, dim=0, keepdim=True)
     rl = ((dyn_reward(p, s, a, fake)[0] - r) ** 2).mean(dim=(1, 2)).sum() + \
          ((dyn_reward(p, s, a, s2)[0] - r) ** 2).mean(dim=(1, 2)).sum()
-    loss = loss + (rl if use_trg else 0.01 * rl)
+    loss = loss + reward_coef * (rl if use_trg else 0.01 * rl)      # (transition_coef / reward_coef: 1, 1 in learn(); see dyn_learn_step_sep_reward)
     return loss, trans, enc_loss, recon, kl_loss
 
 
@@ -554,14 +554,18 @@ class DynTrainState:
         self.lr = lr
 
 
-def dyn_learn_step(st, obs, act, next_obs, rew, noise, use_trg, encoder_loss_coef=1.0, apply=True):
+def dyn_learn_step(st, obs, act, next_obs, rew, noise, use_trg, encoder_loss_coef=1.0, apply=True, with_reward=True):
     """zero_grad -> loss.backward -> Adam.step of one learn() batch (mobody_dynamics.py:641-643).
+    with_reward=False: config inverse_sep_reward_loss = 1 (:637-641) -- reward_loss is neither evaluated nor added, so the reward
+    head's parameters have no gradient (Adam skips them, their step counts stay).
     Returns dict(losses=(5 floats), grads={name: tensor or None})."""
     pr = {k: v.detach().clone().requires_grad_(True) for k, v in st.p.items()}
-    losses = dyn_learn_losses(pr, obs, act, next_obs, rew, noise, use_trg, encoder_loss_coef)
+    losses = dyn_learn_losses(pr, obs, act, next_obs, rew, noise, use_trg, encoder_loss_coef, 1.0, 1.0 if with_reward else 0.0)
     names = list(pr)
     gs = torch.autograd.grad(losses[0], [pr[k] for k in names], allow_unused=True)
     grads = dict(zip(names, gs))
+    if not with_reward:
+        grads = {k: (None if k.startswith("reward_model") else g) for k, g in grads.items()}
     if apply:
         for k, g in grads.items():
             if g is None:
@@ -590,6 +594,27 @@ def dyn_learn_step_together(st, src_rows, trg_rows, noise_src, noise_trg, encode
             st.t[k] += 1
             adam_update(st.p[k], g, st.m[k], st.v[k], st.t[k], st.lr)
     return dict(losses=(float(loss.detach()), float(lt[1].detach()), float(lt[2].detach()), float(lt[4].detach())), grads=grads)
+
+
+def dyn_learn_step_sep_reward(st, src_rows, trg_rows, noise_src, noise_trg, apply=True):
+    """One optimizer step of learn_sep_reward (config inverse_sep_reward_loss = 1, mobody_dynamics.py:482-519):
+    loss = reward_loss(source batch) + reward_loss(target batch) -- no transition or encoder terms -- one backward, one Adam
+    step; the gradient reaches the reward head and, through the fake next state, the encoder, both action encoders and the
+    decoder.  Draws per domain: the forward's state sample (slot 5 of the seven) and the fake-next-state noise (slot 6)."""
+    pr = {k: v.detach().clone().requires_grad_(True) for k, v in st.p.items()}
+    ls = dyn_learn_losses(pr, *src_rows, noise_src, False, 0.0, 0.0, 1.0)
+    lt = dyn_learn_losses(pr, *trg_rows, noise_trg, True, 0.0, 0.0, 1.0)
+    loss = ls[0] + lt[0]
+    names = list(pr)
+    gs = torch.autograd.grad(loss, [pr[k] for k in names], allow_unused=True)
+    grads = dict(zip(names, gs))
+    if apply:
+        for k, g in grads.items():
+            if g is None:
+                continue
+            st.t[k] += 1
+            adam_update(st.p[k], g, st.m[k], st.v[k], st.t[k], st.lr)
+    return dict(losses=(float(loss.detach()),), grads=grads)
 
 
 # --------------------------------------------------------------------------- #

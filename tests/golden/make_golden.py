@@ -659,6 +659,44 @@ def g12t():
     save("g12_together_walker", **out)
 
 
+def g12s():
+    """config inverse_sep_reward_loss = 1: learn() without reward_loss (:637-641; the reward head has no gradient, Adam skips it)
+    and learn_sep_reward (:482-519; reward losses of a source and a target batch only).  Sequence: learn(src), learn(trg),
+    learn_sep_reward(src 24 rows | trg 17 rows), learn(trg) -- losses, every gradient, post-step parameters, per-parameter Adam
+    step counts (the reward head ends at 1, everything else trained every step)."""
+    S, A, bs, bt, seed = 17, 6, 24, 17, 241
+    dyn, m, p = make_dyn_trainer(S, A, seed, inverse_sep_reward_loss=1)
+    out = dict(S=S, A=A, bs=bs, bt=bt, seed=seed, alive_val=0.85, wsum=gi.checksum(p), noise_seed=1500 + seed, lr=1e-3)
+
+    def snap(step):
+        for k, v in m.named_parameters():
+            if v.grad is not None and not k.startswith(("max_", "min_", "elites")):
+                out[f"s{step}_g::{k}"] = sub101(v.grad.numpy())
+            if ".saved_" not in k and not k.startswith(("max_", "min_", "elites", "za_de_")):
+                out[f"s{step}_p::{k}"] = sub101(v.detach().numpy())
+        out[f"s{step}_has_grad"] = np.array(sorted(k for k, v in m.named_parameters() if v.grad is not None))
+
+    with NoiseTap(1500 + seed) as tap, CudaAlias():
+        for step, kind in enumerate(("src", "trg", "sep", "trg")):
+            for v in m.parameters():
+                v.grad = None                                                    # (optim.zero_grad keeps zero tensors: make "no gradient" visible)
+            if kind == "sep":
+                src = gi.pretrain_batch(6000, bs, S, A); trg = gi.pretrain_batch(6001, bt, S, A)
+                res = dyn.learn_sep_reward(*[torch.from_numpy(x) for x in src], *[torch.from_numpy(x) for x in trg], bs)
+                out[f"s{step}_losses"] = np.array([res], np.float64)
+            else:
+                rows = gi.pretrain_batch(6100 + step, bs, S, A)
+                res = dyn.learn(kind == "trg", *[torch.from_numpy(x) for x in rows], bs, 0.01)
+                out[f"s{step}_losses"] = np.array(res, np.float64)
+            snap(step)
+    out["noise_shapes"] = np.array([",".join(map(str, sh)) for sh in tap.shapes])
+    st = dyn.optim.state_dict()["state"]
+    names = [k for k, _ in m.named_parameters()]
+    out["adam_steps"] = np.array([f"{names[i]}={int(float(v['step']))}" for i, v in st.items()])
+    print("inverse_sep", [out[f"s{k}_losses"] for k in range(4)], "noise calls", len(tap.shapes), [x for x in out["adam_steps"] if x.startswith("reward_model1.w")])
+    save("g12_sepreward_walker", **out)
+
+
 def g13(tag="g13_dyn_train", **cfg_over):
     """MOBODYEnsembleDynamics.train (mobody_dynamics.py:731-978) end to end on a tiny data set, max_epochs=2: holdout
     split (random_split), bootstrap indices (torch.randint), per-epoch learn(src) + 3 x learn(trg), validate, per-member
@@ -686,6 +724,11 @@ def g13(tag="g13_dyn_train", **cfg_over):
     print("train: elites", out["elites"], "validate calls", len(rec), "noise calls", len(tap.shapes), "steps", dyn.total_steps)
     print(np.stack(rec)[:, 0])
     save(tag, **out)
+
+
+def g13s():
+    """The g13 run with config inverse_sep_reward_loss = 1 (:935-941: one learn_sep_reward pass per epoch after the three target passes)."""
+    g13("g13_dyn_train_sepreward", inverse_sep_reward_loss=1)
 
 
 def g13t():

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.mobody_abi_version() == 5
+    assert lib.mobody_abi_version() == 6
 
 
 def test_struct_sizes_match_header(lib):

@@ -185,6 +185,82 @@ def test_pretrain_train_together_vs_reference_golden(dev, mfma):
     assert st["t_main"] == 2 and st["t_za"] == {False: 2, True: 2}
 
 
+def test_pretrain_inverse_sep_reward_loss_vs_reference_golden(dev, mfma):
+    """config inverse_sep_reward_loss = 1, step level (fixture g12_sepreward_walker: the reference's learn(src), learn(trg),
+    learn_sep_reward, learn(trg)): the mirror's numbers and parameters; the reward head's Adam count ends at 1."""
+    from test_hip_train import params_close
+    from test_oracle_golden import sep_noise_learn, sep_noise_reward
+    g = gu.load("g12_sepreward_walker")
+    S, A, bs, bt = int(g["S"]), int(g["A"]), int(g["bs"]), int(g["bt"])
+    p = gu.dyn_params_for(g)
+    dyn, m = _mirror_dynamics(p, S, A, dev, dict(inverse_sep_reward_loss=1))
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    td = lambda x: torch.from_numpy(x).to(dev)
+    kind_now = ["src"]
+
+    def noise(b):
+        nz = (sep_noise_reward if kind_now[0] == "sep" else sep_noise_learn)(rng, b, S)
+        return td(np.stack(nz[:6])), td(nz[6])
+
+    dyn.train_noise_fn = noise
+    for step, kind in enumerate(("src", "trg", "sep", "trg")):
+        kind_now[0] = kind
+        if kind == "sep":
+            src = gu.gi.pretrain_batch(6000, bs, S, A); trg = gu.gi.pretrain_batch(6001, bt, S, A)
+            got = [dyn.learn_sep_reward(*[torch.from_numpy(x) for x in src], *[torch.from_numpy(x) for x in trg], bs)]
+        else:
+            rows = gu.gi.pretrain_batch(6100 + step, bs, S, A)
+            got = dyn.learn(kind == "trg", *[torch.from_numpy(x) for x in rows], bs, 0.01)
+        close(np.array(got), g[f"s{step}_losses"], rtol=2e-5, atol=1e-6)
+        sd = m.state_dict()
+        for k in g:
+            if k.startswith(f"s{step}_p::"):
+                params_close(gu.sub101(sd[k.split("::")[1]].cpu().numpy()), g[k], 1e-3)
+    st = m.train_state()
+    assert st["t_main"] == 4 and st["t_rw"] == 1 and st["t_za"] == {False: 2, True: 3}
+
+
+def test_mirror_dynamics_train_sep_reward_vs_reference_golden(dev, mfma):
+    """MOBODYEnsembleDynamics.train with inverse_sep_reward_loss = 1 end to end (fixture g13_dyn_train_sepreward: 32 optimizer
+    steps, per epoch 4 + 3 x 3 learn() steps and 3 learn_sep_reward steps): counts, the four validate() results, elites."""
+    from test_oracle_golden import sep_noise_learn, sep_noise_reward
+    g = gu.load("g13_dyn_train_sepreward")
+    S, A, bs = int(g["S"]), int(g["A"]), int(g["bs"])
+    p = gu.dyn_params_for(g)
+    dyn, m = _mirror_dynamics(p, S, A, dev, dict(inverse_sep_reward_loss=1))
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    td = lambda x: torch.from_numpy(x).to(dev)
+    in_sep = [False]
+    o_sep = dyn._learn_sep_reward_indexed
+
+    def sep_indexed(*a, **k):
+        in_sep[0] = True
+        try:
+            return o_sep(*a, **k)
+        finally:
+            in_sep[0] = False
+
+    dyn._learn_sep_reward_indexed = sep_indexed
+    draws = [0]
+
+    def noise(b):
+        nz = (sep_noise_reward if in_sep[0] else sep_noise_learn)(rng, b, S)
+        draws[0] += 2 if in_sep[0] else 5
+        return td(np.stack(nz[:6])), td(nz[6])
+
+    dyn.train_noise_fn = noise
+    src = gu.gi.batch(901, int(g["n_src"]), S, A); trg = gu.gi.batch(902, int(g["n_trg"]), S, A)
+    torch.manual_seed(int(g["rng_seed"])); np.random.seed(int(g["rng_seed"]))
+    dyn.train(tuple(torch.from_numpy(x) for x in src), tuple(torch.from_numpy(x) for x in trg), max_epochs=2, batch_size=bs)
+    assert dyn.total_steps == int(g["total_steps"]) and draws[0] == int(g["n_noise"])
+    want = g["validate"]
+    got = []
+    for h in dyn.history:
+        got += [h["src_val"], h["trg_val"]]
+    close(np.array(got), want[:, 0], rtol=1e-4, atol=1e-8)
+    assert sorted(int(x) for x in m.elites.tolist()) == sorted(int(x) for x in g["elites"])
+
+
 def test_mirror_dynamics_train_together_vs_reference_golden(dev, mfma):
     """MOBODYEnsembleDynamics.train with train_together = 1 end to end (fixture g13_dyn_train_together: the reference's own
     run, 14 optimizer steps -- per epoch four learn() steps on the source rows, then three joint steps -- no reshuffle of the

@@ -418,3 +418,47 @@ def test_g12_pretraining_steps_train_together():
             close(gu.sub101(v.numpy()), g[f"s{step}_p::{k}"], rtol=1e-5, atol=2e-6)
     want_t = dict(x.split("=") for x in g["adam_steps"])
     assert {k: int(v) for k, v in want_t.items()} == st.t
+
+
+def sep_noise_learn(rng, b, S):
+    """inverse_sep_reward_loss = 1, learn(): encoder_loss's four draws and transition_loss's one; reward_loss is not evaluated
+    (slots 5 and 6 carry zero weight: zeros)."""
+    z = [rng.standard_normal((7, b, 16)).astype(np.float32) for _ in range(5)]
+    return z + [np.zeros((7, b, 16), np.float32), np.zeros((7, b, S), np.float32)]
+
+
+def sep_noise_reward(rng, b, S):
+    """learn_sep_reward: per domain the forward's state sample (slot 5) and the fake-next-state noise (slot 6)."""
+    z = np.zeros((7, b, 16), np.float32)
+    z6 = rng.standard_normal((7, b, 16)).astype(np.float32)
+    return [z, z, z, z, z, z6, rng.standard_normal((7, b, S)).astype(np.float32)]
+
+
+def test_g12_pretraining_steps_inverse_sep_reward_loss():
+    """config inverse_sep_reward_loss = 1: learn() without reward_loss (the reward head has no gradient and keeps its Adam count)
+    and one learn_sep_reward step (reward losses of a source + a target batch only), sequence src, trg, sep, trg."""
+    g = gu.load("g12_sepreward_walker")
+    S, A, bs, bt = int(g["S"]), int(g["A"]), int(g["bs"]), int(g["bt"])
+    p = gu.dyn_params_for(g)
+    st = O.DynTrainState(p, lr=float(g["lr"]))
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    shapes = [tuple(int(x) for x in s.split(",")) for s in g["noise_shapes"]]
+    assert shapes == [(7, bs, 16)] * 10 + [(7, bs, 16), (7, bs, S), (7, bt, 16), (7, bt, S)] + [(7, bs, 16)] * 5
+    for step, kind in enumerate(("src", "trg", "sep", "trg")):
+        if kind == "sep":
+            src = gu.gi.pretrain_batch(6000, bs, S, A); trg = gu.gi.pretrain_batch(6001, bt, S, A)
+            out = O.dyn_learn_step_sep_reward(st, src, trg, sep_noise_reward(rng, bs, S), sep_noise_reward(rng, bt, S))
+            close(np.array(out["losses"]), g[f"s{step}_losses"], rtol=2e-5, atol=1e-6)
+        else:
+            rows = gu.gi.pretrain_batch(6100 + step, bs, S, A)
+            out = O.dyn_learn_step(st, *rows, sep_noise_learn(rng, bs, S), kind == "trg", with_reward=False)
+            close(np.array(out["losses"]), g[f"s{step}_losses"], rtol=2e-5, atol=1e-6)
+        has = sorted(k for k, v in out["grads"].items() if v is not None)
+        assert has == [str(x) for x in g[f"s{step}_has_grad"]]
+        scale = max(float(np.abs(g[k]).max()) for k in g if k.startswith(f"s{step}_g::"))
+        for k in has:
+            close(gu.sub101(out["grads"][k].numpy()), g[f"s{step}_g::{k}"], rtol=1e-4, atol=1e-5 * scale)
+        for k, v in st.p.items():
+            close(gu.sub101(v.numpy()), g[f"s{step}_p::{k}"], rtol=1e-5, atol=2e-6)
+    want_t = dict(x.split("=") for x in g["adam_steps"])
+    assert {k: int(v) for k, v in want_t.items()} == st.t and st.t["reward_model1.weight"] == 1 and st.t["zs1.weight"] == 4
