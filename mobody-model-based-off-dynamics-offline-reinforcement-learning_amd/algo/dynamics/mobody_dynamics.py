@@ -138,8 +138,8 @@ class MOBODYEnsembleDynamics(object):
             raise NotImplementedError("train_together / inverse_sep_reward_loss are supported on one GPU (their joint steps are not sharded)")
         if cfg.get("train_together") and cfg.get("inverse_sep_reward_loss"):
             raise NotImplementedError("train_together together with inverse_sep_reward_loss is not mirrored")
-        if cfg.get("train_with_src_threshold", 1) != 1:
-            raise NotImplementedError("train_with_src_threshold != 1 (data_augmentation) is outside the accelerated path")
+        if cfg.get("train_with_src_threshold", 1) != 1 and self._world()[0] > 1:
+            raise NotImplementedError("train_with_src_threshold != 1 (data_augmentation) is supported on one GPU")
 
     def _sep(self):
         return bool(self.config.get("inverse_sep_reward_loss"))
@@ -300,6 +300,53 @@ class MOBODYEnsembleDynamics(object):
         world, rank = self._world()
         lo, hi = rows * rank // world, rows * (rank + 1) // world
         return start + lo, hi - lo
+
+    # ---- config['train_with_src_threshold'] != 1: data_augmentation, mobody_dynamics.py:660-729 ---------------------------------
+    def update_classifier(self, src_replay_buffer, tar_replay_buffer, batch_size, writer=None):
+        """One step of the augmentation classifier (:660-683): batch_size source rows (label 0) + batch_size target rows
+        (label 1), input noise, cross-entropy on the heads' probabilities, Adam -- the kernels of the DARA classifier
+        (csrc/dara.hip; the reference's row permutation is dropped: the loss is a mean over rows, the noise iid)."""
+        cls = self.classifier
+        s0, a0, n0, _, _ = src_replay_buffer.sample(batch_size)
+        s1, a1, n1, _, _ = tar_replay_buffer.sample(batch_size)
+        s, a, s2 = (torch.cat(x, 0).contiguous() for x in ((s0, s1), (a0, a1), (n0, n1)))
+        (z_sas, x_sas, h1s, h2s), (z_sa, x_sa, h1a, h2a) = cls.logits(s, a, s2, True, seed=(self.seed + 57) & 0xFFFFFFFF, save=True)
+        dz_sas, dz_sa, loss = ops.dara_loss_grad(z_sas[0], z_sa[0], batch_size, None)
+        for net, opt, dz, x, h1, h2 in ((cls.sas_classifier, cls.opt_sas, dz_sas, x_sas, h1s, h2s),
+                                        (cls.sa_classifier, cls.opt_sa, dz_sa, x_sa, h1a, h2a)):
+            self._cls_ws = ops.mlp3_backward(net.blob_T, net.in_dim, 2, 1, dz, x, h1, h2, opt.grad, getattr(self, "_cls_ws", None))
+            opt.step()
+        return loss[0], loss[1]
+
+    def data_augmentation(self, buffer):
+        """:685-729: train a domain classifier for 8 000 steps of 256 + 256 rows, then every SOURCE row whose sas head says
+        "target" with probability above config['train_with_src_threshold'] -- after the reference's second softmax over the
+        head's probabilities (F.softmax(sas_logits) where the "logits" already are softmax outputs, :701) -- is kept in
+        `src_replay_buffer_sim_trg`; train() adds those rows to the target TRAINING set (:797-812)."""
+        from ..offline_offline.mobody import _Classifier
+        src_rb, tar_rb = buffer
+        m = self.model
+        cfg = self.config
+        self.classifier = _Classifier(m.obs_dim, m.action_dim, m.device, cfg["gaussian_noise_std"], cfg["actor_lr"])
+        for _ in range(8000):
+            self.update_classifier(src_rb, tar_rb, 256, None)
+        s, a, s2, r, nd = src_rb.sample_all()
+        s, a, s2 = s.contiguous(), a.contiguous(), s2.contiguous()
+        z_sas, _ = self.classifier.logits(s, a, s2, False)
+        probs = torch.softmax(torch.softmax(z_sas[0], -1), -1)[:, 1]
+        include = probs > float(cfg["train_with_src_threshold"])
+        self.augment_probs, self.augment_include = probs, include
+        sim = [x[include].contiguous() for x in (s, a, s2, r.reshape(-1, 1))]
+
+        class _Sim(object):                               # what train() reads of the reference's second ReplayBuffer
+            size = int(include.sum())
+
+            @staticmethod
+            def sample_all(cuda=True):
+                return sim[0], sim[1], sim[2], sim[3], None
+
+        self.src_replay_buffer_sim_trg = _Sim()
+        print("number of added data", _Sim.size)
 
     # ---- config['inverse_sep_reward_loss'] = 1: learn_sep_reward, mobody_dynamics.py:482-519 -----------------------------------
     def _learn_sep_reward_batch(self, src, trg):
@@ -522,6 +569,9 @@ class MOBODYEnsembleDynamics(object):
         self._check_pretrain_config()
         m = self.model
         dev = m.device
+        augment = self.config.get("train_with_src_threshold", 1) != 1
+        if augment:                                                                         # :745-746
+            self.data_augmentation(buffer)
         self.src_replay_buffer = src_data
         self.total_steps = 0
         self._pre_graphs.clear()                          # graphs of an earlier train() call captured that call's tensors
@@ -549,6 +599,10 @@ class MOBODYEnsembleDynamics(object):
         trg_tr = [x[ix(t_tr)].contiguous() for x in trg]; trg_ho = [x[ix(t_ho)].contiguous() for x in trg]
         self.obs_scaler.fit(None)                                                           # identity (Q4)
         n_s, n_t = n_src - src_hold, n_trg - trg_hold
+        if augment:                                                                         # :797-812: the selected source rows join
+            sim = self.src_replay_buffer_sim_trg.sample_all()                               # the target TRAINING set (not the holdout)
+            trg_tr = [torch.cat([x, y.to(dev).reshape(len(y), -1)], 0).contiguous() for x, y in zip(trg_tr, sim[:4])]
+            n_t = trg_tr[0].shape[0]
         E = m.num_ensemble
         trg_holdout_losses = [1e10 for _ in range(E)]
         src_idx = bc(torch.randint(n_s, size=[E, n_s]).to(device=dev, dtype=torch.int32)).contiguous()   # :826-827 (CPU generator)

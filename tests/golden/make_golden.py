@@ -442,10 +442,18 @@ class CudaAlias:
             return self._to(t, *a, **k)
 
         torch.Tensor.to = to
+        self._mto = torch.nn.Module.to
+
+        def mto(mod, *a, **k):                       # Classifier(...).to('cuda') in data_augmentation (:688)
+            a = tuple("cpu" if (isinstance(x, str) and x.startswith("cuda")) else x for x in a)
+            return self._mto(mod, *a, **k)
+
+        torch.nn.Module.to = mto
         return self
 
     def __exit__(self, *a):
         torch.Tensor.to = self._to
+        torch.nn.Module.to = self._mto
 
 
 REFRESH_MAP = {50000: 96, 2000: 40, 100: 12}     # hard-coded refresh sizes (mobody.py:442-443,484-485) -> fixture sizes
@@ -729,6 +737,75 @@ def g13(tag="g13_dyn_train", **cfg_over):
 def g13s():
     """The g13 run with config inverse_sep_reward_loss = 1 (:935-941: one learn_sep_reward pass per epoch after the three target passes)."""
     g13("g13_dyn_train_sepreward", inverse_sep_reward_loss=1)
+
+
+def g13a():
+    """config train_with_src_threshold != 1 (data_augmentation, mobody_dynamics.py:685-729, and train()'s concatenation :797-812):
+    a domain classifier is trained for 8 000 steps on batches of 256 + 256 rows, every source row whose sas head says "target"
+    with probability above the threshold (after the reference's second softmax) joins the target TRAINING set, then train()
+    runs as usual (max_epochs = 1 here).  The classifier's 8 000 chained noisy steps are not a parity target; the fixture holds
+    the trained classifier, the threshold (placed in the widest gap of the sorted probabilities), the selected rows and what
+    train() made of them -- the mirror is checked from the trained classifier on."""
+    S, A, bs = 17, 6, 32
+    import algo.dynamics.mobody_dynamics as md
+    extra = dict(state_dim=S, action_dim=A, hidden_sizes=256, gaussian_noise_std=1.0, actor_lr=3e-4)
+    src = gi.batch(901, 150, S, A); trg = gi.batch(902, 90, S, A)
+    trg[0][:, 2] += 0.6; trg[2][:, 2] += 0.6                      # a shifted state dimension: the domains are separable to a degree
+
+    def rb_of(rows):
+        rb = ref_utils.ReplayBuffer(S, A, "cpu", max_size=len(rows[0]))
+        rb.add_batch(dict(obss=torch.from_numpy(rows[0]), next_obss=torch.from_numpy(rows[2]), actions=torch.from_numpy(rows[1]),
+                          rewards=torch.from_numpy(rows[3]), terminals=torch.from_numpy(rows[4])))
+        return rb
+
+    # pass 1: train the classifier exactly as data_augmentation does, read the probabilities, place the threshold in a gap
+    dyn, m, p = make_dyn_trainer(S, A, 221, train_with_src_threshold=0.5, **extra)
+    torch.manual_seed(43); np.random.seed(43)
+    with NoiseTap(1600) as tap, CudaAlias():
+        o_rb = md.utils.ReplayBuffer if hasattr(md, "utils") else None
+        dyn.data_augmentation((rb_of(src), rb_of(trg)))
+        cls_sd = {k: v.detach().clone() for k, v in dyn.classifier.state_dict().items()}
+        with torch.no_grad():
+            sas, _ = dyn.classifier(torch.from_numpy(src[0]), torch.from_numpy(src[1]), torch.from_numpy(src[2]), with_noise=False)
+            probs = torch.softmax(sas, -1)[:, 1].numpy()
+    sp = np.sort(probs)
+    lo, hi = int(0.3 * len(sp)), int(0.8 * len(sp))
+    j = lo + int(np.argmax(np.diff(sp[lo:hi])))
+    thr = float(0.5 * (sp[j] + sp[j + 1]))
+    print("probs range", sp[0], sp[-1], "threshold", thr, "gap", sp[j + 1] - sp[j], "selected", int((probs > thr).sum()))
+    # pass 2: the whole train() with that threshold and the SAME trained classifier (data_augmentation's training loop is cut to
+    # zero steps harness-side by handing it a classifier that is already trained)
+    dyn, m, p = make_dyn_trainer(S, A, 221, train_with_src_threshold=thr, **extra)
+    rec = []
+    o_val = dyn.validate
+
+    def validate(*a, **k):
+        r = o_val(*a, **k); rec.append(np.array([r[0], r[1]], np.float64)); return r
+
+    dyn.validate = validate
+    o_upd = dyn.update_classifier
+    state = dict(loaded=False)
+
+    def upd(*a, **k):                                                # the 8 000 calls: load the trained weights once, train nothing
+        if not state["loaded"]:
+            dyn.classifier.load_state_dict(cls_sd); state["loaded"] = True
+        z = torch.zeros(())
+        return z, z
+
+    dyn.update_classifier = upd
+    torch.manual_seed(41); np.random.seed(41)
+    with NoiseTap(1300) as tap, CudaAlias():
+        dyn.train(tuple(torch.from_numpy(x) for x in src[:4]), tuple(torch.from_numpy(x) for x in trg[:4]), max_epochs=1, batch_size=bs,
+                  buffer=(rb_of(src), rb_of(trg)))
+    sim = dyn.src_replay_buffer_sim_trg
+    out = dict(S=S, A=A, bs=bs, seed=221, alive_val=0.85, wsum=gi.checksum(p), noise_seed=1300, rng_seed=41, lr=1e-3, n_src=150, n_trg=90,
+               threshold=thr, probs=probs.astype(np.float64), include=(probs > thr), n_added=int(sim.size),
+               sim_state=sim.state[:sim.size].numpy(), validate=np.stack(rec), elites=m.state_dict()["elites"].numpy(),
+               n_noise=len(tap.shapes), total_steps=dyn.total_steps, trg_shift=0.6)
+    for k, v in cls_sd.items():
+        out["cls::" + k] = v.numpy()
+    print("augmentation: added", out["n_added"], "steps", dyn.total_steps, "noise calls", len(tap.shapes))
+    save("g13_dyn_train_augment", **out)
 
 
 def g13t():

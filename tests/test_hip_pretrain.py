@@ -261,6 +261,83 @@ def test_mirror_dynamics_train_sep_reward_vs_reference_golden(dev, mfma):
     assert sorted(int(x) for x in m.elites.tolist()) == sorted(int(x) for x in g["elites"])
 
 
+def test_mirror_dynamics_train_augmented_vs_reference_golden(dev, mfma):
+    """config train_with_src_threshold != 1 (data_augmentation + train(), fixture g13_dyn_train_augment from the reference's own
+    run): checked FROM THE TRAINED CLASSIFIER ON -- its 8 000 chained noisy steps are not a parity target (one step is, G9), so
+    the fixture's classifier is loaded in place of training, exactly as the fixture's second pass did.  The probabilities of
+    every source row (the double softmax), the selected rows, the enlarged target training set's effect on train(): step
+    count, validate() results, elites."""
+    from mobody_amd.algo.utils import ReplayBuffer
+    g = gu.load("g13_dyn_train_augment")
+    S, A, bs, thr = int(g["S"]), int(g["A"]), int(g["bs"]), float(g["threshold"])
+    p = gu.dyn_params_for(g)
+    dyn, m = _mirror_dynamics(p, S, A, dev, dict(train_with_src_threshold=thr))
+    rng = gu.gi.noise_stream(int(g["noise_seed"]))
+    td = lambda x: torch.from_numpy(x).to(dev)
+
+    def noise(b):
+        nz = noise7(rng, b, S)
+        return td(np.stack(nz[:6])), td(nz[6])
+
+    dyn.train_noise_fn = noise
+    src = gu.gi.batch(901, int(g["n_src"]), S, A); trg = gu.gi.batch(902, int(g["n_trg"]), S, A)
+    trg[0][:, 2] += float(g["trg_shift"]); trg[2][:, 2] += float(g["trg_shift"])
+
+    def rb_of(rows):
+        rb = ReplayBuffer(S, A, dev, max_size=len(rows[0]))
+        rb.add_batch(dict(obss=torch.from_numpy(rows[0]), next_obss=torch.from_numpy(rows[2]), actions=torch.from_numpy(rows[1]),
+                          rewards=torch.from_numpy(rows[3]), terminals=torch.from_numpy(rows[4])))
+        return rb
+
+    calls = [0]
+
+    def upd(*a, **k):                                      # the 8 000 calls: load the reference-trained weights once, train nothing
+        if calls[0] == 0:
+            dyn.classifier.load_state_dict({k_[5:]: td(np.ascontiguousarray(g[k_])) for k_ in g if k_.startswith("cls::")})
+        calls[0] += 1
+        return None, None
+
+    dyn.update_classifier = upd
+    torch.manual_seed(int(g["rng_seed"])); np.random.seed(int(g["rng_seed"]))
+    dyn.train(tuple(torch.from_numpy(x) for x in src[:4]), tuple(torch.from_numpy(x) for x in trg[:4]), max_epochs=1, batch_size=bs,
+              buffer=(rb_of(src), rb_of(trg)))
+    assert calls[0] == 8000
+    close(dyn.augment_probs, g["probs"], rtol=1e-5, atol=1e-6)
+    assert np.array_equal(dyn.augment_include.cpu().numpy(), g["include"]) and dyn.src_replay_buffer_sim_trg.size == int(g["n_added"])
+    assert torch.equal(dyn.src_replay_buffer_sim_trg.sample_all()[0].cpu(), torch.from_numpy(g["sim_state"]))
+    assert dyn.total_steps == int(g["total_steps"]) and dyn._train_calls == int(g["n_noise"]) // 7
+    got = []
+    for h in dyn.history:
+        got += [h["src_val"], h["trg_val"]]
+    close(np.array(got), g["validate"][:, 0], rtol=1e-4, atol=1e-8)
+    assert sorted(int(x) for x in m.elites.tolist()) == sorted(int(x) for x in g["elites"])
+
+
+def test_data_augmentation_trains_its_classifier(dev):
+    """The un-patched path: 8 000 classifier steps on the device, then the selection -- no parity target, only that it runs, that
+    the classifier has learnt the (shifted) domains apart and that the threshold cuts the source rows."""
+    from mobody_amd.algo.utils import ReplayBuffer
+    S, A = 17, 6
+    dyn, m = _mirror_dynamics(gu.gi.dyn_params(5, S, A), S, A, dev, dict(train_with_src_threshold=0.45))
+    src = gu.gi.batch(901, 400, S, A); trg = gu.gi.batch(902, 200, S, A)
+    trg[0][:, 2] += 2.0; trg[2][:, 2] += 2.0
+
+    def rb_of(rows):
+        rb = ReplayBuffer(S, A, dev, max_size=len(rows[0]), rng="device", seed=3)
+        rb.add_batch(dict(obss=torch.from_numpy(rows[0]), next_obss=torch.from_numpy(rows[2]), actions=torch.from_numpy(rows[1]),
+                          rewards=torch.from_numpy(rows[3]), terminals=torch.from_numpy(rows[4])))
+        return rb
+
+    dyn.data_augmentation((rb_of(src), rb_of(trg)))
+    pr = dyn.augment_probs
+    assert torch.isfinite(pr).all() and 0.26 < float(pr.min()) and float(pr.max()) < 0.74          # softmax of a probability pair
+    s, a, s2 = (torch.from_numpy(x).to(dev) for x in (trg[0], trg[1], trg[2]))
+    z, _ = dyn.classifier.logits(s.contiguous(), a.contiguous(), s2.contiguous(), False)
+    pt = torch.softmax(torch.softmax(z[0], -1), -1)[:, 1]
+    assert float(pt.mean()) > float(pr.mean()) + 0.1                                               # target rows look like target rows
+    assert dyn.src_replay_buffer_sim_trg.size == int((pr > 0.45).sum()) < 400
+
+
 def test_mirror_dynamics_train_together_vs_reference_golden(dev, mfma):
     """MOBODYEnsembleDynamics.train with train_together = 1 end to end (fixture g13_dyn_train_together: the reference's own
     run, 14 optimizer steps -- per epoch four learn() steps on the source rows, then three joint steps -- no reshuffle of the
