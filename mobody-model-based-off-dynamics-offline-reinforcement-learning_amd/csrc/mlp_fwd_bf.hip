@@ -112,27 +112,34 @@ __device__ __forceinline__ void mlp3_fwd_bf_tile(const Mlp3FwdArgs& a, int m, fl
 }
 
 // one or two independent networks per launch (blockIdx.y < members_a -> net a), as k_mlp3_fwd2
-template <int ACT, int PM, int RG, int NT, bool DS = false, int MT = 1>
+// NT / NT2: output-layer width (16-column tiles; 0 = any) of net a / net b -- a twin-Q (one output) and an actor with more than
+// 16 actions (pen: 24) still share a launch
+template <int ACT, int PM, int RG, int NT, bool DS = false, int MT = 1, int NT2 = NT>
 __global__ __launch_bounds__(NTHREADS * RG, (PM == 4 && RG == 1 && !DS && MT == 1) ? FWD_F16_WAVES : 2) void k_mlp3_fwd_bf(Mlp3FwdArgs a, Mlp3FwdArgs b, int members_a) {
   extern __shared__ __attribute__((aligned(16))) float Xs[];
   const bool second = (int)blockIdx.y >= members_a;
   const Mlp3FwdArgs s = second ? b : a;
   if ((long long)blockIdx.x * (32 * MT * RG) >= s.rows) return;
-  mlp3_fwd_bf_tile<ACT, PM, RG, NT, DS, MT>(s, second ? (int)blockIdx.y - members_a : (int)blockIdx.y, Xs);
+  if constexpr (NT2 == NT) {
+    mlp3_fwd_bf_tile<ACT, PM, RG, NT, DS, MT>(s, second ? (int)blockIdx.y - members_a : (int)blockIdx.y, Xs);
+  } else {
+    if (second) mlp3_fwd_bf_tile<ACT, PM, RG, NT2, DS, MT>(s, (int)blockIdx.y - members_a, Xs);
+    else mlp3_fwd_bf_tile<ACT, PM, RG, NT, DS, MT>(s, (int)blockIdx.y, Xs);
+  }
 }
 
-template <int ACT, int PM, int RG, int NT, bool DS = false, int MT = 1>
+template <int ACT, int PM, int RG, int NT, bool DS = false, int MT = 1, int NT2 = NT>
 static int launch_bf_t(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b, int members_b, hipStream_t st) {
   constexpr size_t lds = split_lds_bytes<PM, 32 * MT * RG>();
   static bool once = false;
   if (!once) {
-    int rc = allow_big_lds(k_mlp3_fwd_bf<ACT, PM, RG, NT, DS, MT>, 160 * 1024);
+    int rc = allow_big_lds(k_mlp3_fwd_bf<ACT, PM, RG, NT, DS, MT, NT2>, 160 * 1024);
     if (rc) return rc;
     once = true;
   }
   const long long rows = a.rows > b.rows ? a.rows : b.rows;
   ProfScope prof(PROF_MLP_FWD, st);
-  hipLaunchKernelGGL((k_mlp3_fwd_bf<ACT, PM, RG, NT, DS, MT>), dim3((unsigned)cdiv(rows, 32 * MT * RG), (unsigned)(members_a + members_b)),
+  hipLaunchKernelGGL((k_mlp3_fwd_bf<ACT, PM, RG, NT, DS, MT, NT2>), dim3((unsigned)cdiv(rows, 32 * MT * RG), (unsigned)(members_a + members_b)),
                      dim3(NTHREADS * RG), lds, st, a, b, members_a);
   MB_LAUNCH_OK("k_mlp3_fwd_bf");
   return 0;
@@ -140,6 +147,11 @@ static int launch_bf_t(const Mlp3FwdArgs& a, int members_a, const Mlp3FwdArgs& b
 
 template <int ACT, int PM, int RG>
 static int launch_bf_nt(const Mlp3FwdArgs& a, int ma, const Mlp3FwdArgs& b, int mb, hipStream_t st) {
+  if (RG == 1 && PM == 4 && mb > 0 && b.rows > 0 && a.rows > 0 && a.Np3 != b.Np3) {     // two nets, two output widths (16 | 32)
+    if (a.Np3 == 16 && b.Np3 == 32) return launch_bf_t<ACT, PM, RG, 1, false, 1, 2>(a, ma, b, mb, st);
+    if (a.Np3 == 32 && b.Np3 == 16) return launch_bf_t<ACT, PM, RG, 2, false, 1, 1>(a, ma, b, mb, st);
+    return fail(MOBODY_E_ARG, "launch_mlp3_fwd_bf: nets of output widths %d and %d do not share a launch", a.Np3, b.Np3);
+  }
   const int np3 = a.rows > 0 ? a.Np3 : b.Np3;
   return np3 == 16 ? launch_bf_t<ACT, PM, RG, 1>(a, ma, b, mb, st) : np3 == 32 ? launch_bf_t<ACT, PM, RG, 2>(a, ma, b, mb, st)
                                                                               : launch_bf_t<ACT, PM, RG, 0>(a, ma, b, mb, st);

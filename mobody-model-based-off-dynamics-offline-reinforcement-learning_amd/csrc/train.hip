@@ -228,7 +228,9 @@ static Mlp3FwdArgs fwd_args(const float* blob, const MobodyMlpLayout& L, const f
 // two ReLU nets in one launch at the requested precision (0 = exact fp32 MFMA)
 static int fwd_pair(const Mlp3FwdArgs& a, int ma, const Mlp3FwdArgs& b, int mb, int prec, hipStream_t st) {
   if (prec == 0) return launch_mlp3_fwd_pair(a, ma, b, mb, st);
-  if (a.rows > 0 && b.rows > 0 && a.Np3 != b.Np3) {   // the merged kernel is specialised on one output-layer width
+  // (one launch also when the two output layers differ in width, 16 | 32 columns, in the f16x2 mode; else one launch per net)
+  const bool mixed_ok = prec == 4 && ((a.Np3 == 16 && b.Np3 == 32) || (a.Np3 == 32 && b.Np3 == 16));
+  if (a.rows > 0 && b.rows > 0 && a.Np3 != b.Np3 && !mixed_ok) {
     int rc = launch_mlp3_fwd_bf(a, ma, Mlp3FwdArgs{}, 0, ACT_RELU, prec, st);
     return rc ? rc : launch_mlp3_fwd_bf(b, mb, Mlp3FwdArgs{}, 0, ACT_RELU, prec, st);
   }
