@@ -1,3 +1,4 @@
+# Instruction / wait counters of the bare twin-Q forward (tools/probe/micro_pipe.py 15360) in three rocprofv3 --pmc passes.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_insts; mkdir -p $O
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d $O/a -- python3 tools/probe/micro_pipe.py 15360 > /dev/null 2> $O/a.err

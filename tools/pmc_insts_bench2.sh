@@ -1,3 +1,4 @@
+# Vector-instruction mix by type per train-step kernel (eager c2 bench under rocprofv3 --pmc, two passes), per wave.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_insts_b2; mkdir -p $O
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT SQ_WAVES --output-format csv -d $O/a -- python3 bench.py --steps 40 --warmup 3 --no_cpu_baseline --no_mode_sweep --graph 0 > /dev/null 2> $O/a.err

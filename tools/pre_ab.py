@@ -1,3 +1,5 @@
+"""Pre-training step time, HIP-graph replay against eager launches (the side stream is a build flag of csrc/pretrain.hip:
+bash tools/ab_build.sh pretrain.hip "-DPRE_SIDE_STREAM=0").  GPU box:  TAG=label python tools/pre_ab.py"""
 import sys, time, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch

@@ -1,3 +1,5 @@
+# Phase traces of LONE workgroups (2 560 rows: one workgroup per CU) for the forward, critic backward and actor backward in the
+# f16x2 mode -- what a launch of <= 256 tiles (c1, pre-training) is made of.  GPU box: bash tools/trace_small.sh (trace build)
 set -e
 cd $GRAFT_REPO_ROOT
 MOBODY_TRACE=1 python - <<PY
