@@ -312,6 +312,15 @@ int mobody_actor_backward(const MobodyTrainDims* d, const MobodyHyper* h, const 
                           float* loss_out, float* workspace, void* stream);
 /* v_true: NULL -> BC weights exp(3*q_b/mean|q_b|); [Nt] V(s_true) -> exp(3*(q_b - V)) (config['advantage'], :255-256). */
 
+/* mobody_critic_update in two calls: phase 1 enqueues its forwards (none of them reads `reward`), phase 2 the backward, the
+ * weight gradients and the reduction / optimizer step.  Between the two the caller may join a stream that rewrites `reward`
+ * (penalty_type 'par', mobody.py:428-434: an ensemble step on the source rows that otherwise sits in front of the critic). */
+int mobody_critic_update_phase(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob, const float* actor_blob_T,
+                               float* q_blob, float* q_blob_T, float* qtarg_blob, float* qtarg_blob_T, const float* state,
+                               const float* action, const float* next_state, const float* reward, const float* not_done,
+                               const float* q_next, float* m, float* v, int64_t t, const int64_t* t_dev, float lr, float* loss_out,
+                               float* workspace, int policy_forward, int64_t* bump, int phase, void* stream);
+
 /* Single-GPU form of mobody_actor_backward + mobody_adam_polyak (mobody.py:554-578), as mobody_critic_update. */
 int mobody_actor_update(const MobodyTrainDims* d, const MobodyHyper* h, float* actor_blob, float* actor_blob_T,
                         const float* q_blob, const float* q_blob_T, const float* state, const float* action,

@@ -99,6 +99,8 @@ PROTOTYPES = {
                                      vp, vp, vp, vp, vp, vp, C.c_int, vp]),
     "mobody_critic_update": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, i64, vp, f32, vp, vp, C.c_int, vp, vp]),
+    "mobody_critic_update_phase": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                             vp, vp, vp, vp, vp, i64, vp, f32, vp, vp, C.c_int, vp, C.c_int, vp]),
     "mobody_actor_update": (C.c_int, [C.POINTER(MobodyTrainDims), C.POINTER(MobodyHyper), vp, vp, vp, vp, vp, vp, vp,
                                       vp, vp, vp, i64, vp, f32, vp, vp, vp]),
     "mobody_value_loss_grad": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp]),

@@ -482,6 +482,24 @@ class MOBODY(object):
             # step counts (it does not read them), the critic's optimizer launch advances c[0] (the gather is done with it)
             ops.gather_batch_rng([rb._fields() for rb in bufs], cnts, seeds, [1] * len(bufs), c[0:1],
                                  [rb.ptr_size[1:2] for rb in bufs], S, A, b, bump=(c[1:2], c[2:3], c[3:4]))
+            if par and not cfg["advantage"] and int(cfg.get("par_overlap", 1)):
+                # The ensemble step that relabels the source rewards (mobody.py:428-434) runs on a side stream NEXT TO the
+                # critic's forwards -- none of them reads the rewards, the TD error in the backward's prologue is the first
+                # reader -- and is joined before the backward: its launches (a few hundred workgroups each) and the forwards'
+                # fill each other's idle issue slots.  In the captured graph the side stream is a parallel branch.
+                main = torch.cuda.current_stream()
+                if getattr(self, "_side_stream", None) is None:
+                    self._side_stream = torch.cuda.Stream(device=self.device)
+                side = self._side_stream
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    par_relabel(1)
+                self.critic_update(b, N, Nt, t_dev=c[1:2], bump=c[0:1], phase=1)
+                main.wait_stream(side)
+                self.critic_update(b, N, Nt, t_dev=c[1:2], bump=c[0:1], phase=2)
+                self.actor_stats(b, N, Nt, N, Nt)
+                self.actor_update(b, N, Nt, t_dev=c[2:3])
+                return
             if par:
                 par_relabel(1)
             if cfg["advantage"]:                                             # V update first (mobody.py:533-537)
@@ -723,19 +741,21 @@ class MOBODY(object):
         between); not in the advantage variant, whose critic call has no target-Q launch."""
         return not self.config["advantage"]
 
-    def critic_update(self, b, N, Nt, t_dev=None, bump=None):
-        """critic_grad + critic_apply in the fused single-GPU form (same arithmetic, no gradient blob)."""
+    def critic_update(self, b, N, Nt, t_dev=None, bump=None, phase=0):
+        """critic_grad + critic_apply in the fused single-GPU form (same arithmetic, no gradient blob).  phase 1 / 2: only its
+        forwards / only the backward + update (ops.critic_update)."""
         dims, hyp = self._dims(N, Nt, N, Nt)
         q_next = None
         if self.config["advantage"]:
+            assert phase == 0, "the phased critic update is not used with the V-function target"
             q_next = ops.mlp3_forward(self.v_func.blob, self.S, 1, 1, b[2]).view(N)
         o = self.q_optimizer
-        if t_dev is None:
+        if t_dev is None and phase != 2:
             o.t += 1
         ops.critic_update(dims, hyp, self.policy.blob, self.q_funcs.blob, self.q_funcs.blob_T, self.target_q_funcs.blob, b,
                           o.m, o.v, o.t, o.lr, self._loss[0:1], self._ws, q_next=q_next, t_dev=t_dev,
                           policy_forward=self._policy_rides_along(), actor_blob_T=self.policy.blob_T,
-                          qtarg_blob_T=self.target_q_funcs.blob_T, bump=bump)
+                          qtarg_blob_T=self.target_q_funcs.blob_T, bump=bump, phase=phase)
 
     def actor_update(self, b, N, Nt, t_dev=None):
         dims, hyp = self._dims(N, Nt, N, Nt)

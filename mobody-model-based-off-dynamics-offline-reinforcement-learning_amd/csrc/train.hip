@@ -289,7 +289,10 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
                        const float* state, const float* action,
                        const float* next_state, const float* reward, const float* not_done, const float* q_next,
                        float* grad_q, const AdamTarget& adam, float* loss_out, float* workspace, int policy_forward,
-                       void* stream) {
+                       void* stream, int phase = 0) {
+  // phase: 0 the whole step; 1 only its forwards (nothing of them reads `reward`); 2 only the backward, weight gradients and
+  // reduction / optimizer step -- the caller may let another stream finish rewriting `reward` (penalty_type 'par': an ensemble
+  // step on the source rows) between the two
   int rc = check_dims(d, "mobody_critic_step");
   if (rc) return rc;
   MB_REQUIRE(h && q_blob && q_blob_T && state && action && reward && not_done && (grad_q || adam.on) && loss_out && workspace,
@@ -308,7 +311,9 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
   // online twin-Q(s, a), activations kept for the backward (:196), together with a' = pi(s') (:191) in one launch
   const Mlp3FwdArgs fq = fwd_args(q_blob, w.Lq, state, S, action, A, N, w.q, 0, 1.f, w.xq, w.h1q, w.h2q, w.mq1, w.mq2, qT,
                                   prec == 4 ? w.eh1q : nullptr);
-  if (q_next == nullptr) {
+  if (phase == 2) {
+    // forwards already enqueued by the phase-1 call
+  } else if (q_next == nullptr) {
     rc = fwd_pair(fq, 2, fwd_args(actor_blob, w.La, next_state, S, nullptr, 0, N, w.pin, 1, h->max_action, nullptr, nullptr, nullptr, nullptr, nullptr, aT), 1, prec, st);
     // target twin-Q(s', a') (:192) -- and, when the caller asks for it, pi(s) of the coming actor phase in the same
     // launch: the actor is not updated in between, and a twin-Q launch alone is 2.5 workgroups per CU where the
@@ -322,7 +327,7 @@ static int critic_impl(const MobodyTrainDims* d, const MobodyHyper* h, const flo
   } else {
     rc = fwd_one(fq, 2, prec, st);                  // q_next = V(s') supplied by the caller (update_q_functions_1, :210-229)
   }
-  if (rc) return rc;
+  if (rc || phase == 1) return rc;
   const float invNg = 1.f / (float)d->N_global;
   // TD error -> dz3 in the backward's prologue (mobody.py:190-207), then dz2, dz1 and the bias partials
   Mlp3BwdArgs bq = bwd_args(w.Lq, q_blob_T, w.dz3q, w.h1q, w.h2q, N, w.dz2, w.dz1, w.dbp, w.mq1, w.mq2, prec, w.edz2);
@@ -360,6 +365,23 @@ extern "C" int mobody_critic_update(const MobodyTrainDims* d, const MobodyHyper*
   at.bump = (long long*)bump;
   return critic_impl(d, h, actor_blob, actor_blob_T, q_blob, q_blob_T, qtarg_blob, qtarg_blob_T, state, action, next_state, reward,
                      not_done, q_next, nullptr, at, loss_out, workspace, policy_forward, stream);
+}
+
+extern "C" int mobody_critic_update_phase(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,
+                                          const float* actor_blob_T, float* q_blob, float* q_blob_T, float* qtarg_blob,
+                                          float* qtarg_blob_T, const float* state, const float* action, const float* next_state,
+                                          const float* reward, const float* not_done, const float* q_next, float* m, float* v,
+                                          int64_t t, const int64_t* t_dev, float lr, float* loss_out, float* workspace,
+                                          int policy_forward, int64_t* bump, int phase, void* stream) {
+  MB_REQUIRE(h && q_blob && q_blob_T && qtarg_blob && m && v, "mobody_critic_update_phase: null pointer");
+  MB_REQUIRE(phase == 1 || phase == 2, "mobody_critic_update_phase: phase is 1 (forwards) or 2 (backward + update)");
+  MB_REQUIRE(t_dev != nullptr || t >= 1, "mobody_critic_update_phase: step t must be >= 1");
+  MB_REQUIRE(bump == nullptr || bump != t_dev, "mobody_critic_update_phase: bump must not be the step word the launch reads");
+  AdamTarget at = adam_target(q_blob, q_blob_T, m, v, qtarg_blob, t, t_dev, lr, h->tau, 1.f, h->precision);
+  at.target_T = qtarg_blob_T;
+  at.bump = (long long*)bump;
+  return critic_impl(d, h, actor_blob, actor_blob_T, q_blob, q_blob_T, qtarg_blob, qtarg_blob_T, state, action, next_state, reward,
+                     not_done, q_next, nullptr, at, loss_out, workspace, policy_forward, stream, phase);
 }
 
 extern "C" int mobody_actor_forward(const MobodyTrainDims* d, const MobodyHyper* h, const float* actor_blob,

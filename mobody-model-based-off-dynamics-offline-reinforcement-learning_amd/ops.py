@@ -179,15 +179,18 @@ def actor_backward(dims, hyp, actor_blob, actor_blob_T, q_blob, q_blob_T, state,
 
 
 def critic_update(dims, hyp, actor_blob, q_blob, q_blob_T, qtarg_blob, batch, m, v, t, lr, loss_out, ws, q_next=None,
-                  t_dev=None, policy_forward=False, actor_blob_T=None, qtarg_blob_T=None, bump=None):
+                  t_dev=None, policy_forward=False, actor_blob_T=None, qtarg_blob_T=None, bump=None, phase=0):
     """critic_step + Adam + Polyak in the fused single-GPU form (t: host step count, or t_dev: device int64[1]);
-    bump: device int64[1] word (not t_dev) the optimizer launch increments by one."""
+    bump: device int64[1] word (not t_dev) the optimizer launch increments by one.  phase 1 / 2: only the forwards / only the
+    backward + update (mobody_critic_update_phase: the caller joins whatever rewrites `reward` in between)."""
     s, a, s2, r, nd = batch
-    check(load().mobody_critic_update(C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(actor_blob_T), ptr(q_blob), ptr(q_blob_T),
-                                      ptr(qtarg_blob), ptr(qtarg_blob_T), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(q_next), ptr(m),
-                                      ptr(v), int(t), ptr(t_dev), float(lr), ptr(loss_out), ptr(ws),
-                                      int(bool(policy_forward)), ptr(bump), cur_stream()),
-          "mobody_critic_update")
+    args = (C.byref(dims), C.byref(hyp), ptr(actor_blob), ptr(actor_blob_T), ptr(q_blob), ptr(q_blob_T),
+            ptr(qtarg_blob), ptr(qtarg_blob_T), ptr(s), ptr(a), ptr(s2), ptr(r), ptr(nd), ptr(q_next), ptr(m),
+            ptr(v), int(t), ptr(t_dev), float(lr), ptr(loss_out), ptr(ws), int(bool(policy_forward)), ptr(bump))
+    if phase:
+        check(load().mobody_critic_update_phase(*args, int(phase), cur_stream()), "mobody_critic_update_phase")
+    else:
+        check(load().mobody_critic_update(*args, cur_stream()), "mobody_critic_update")
 
 
 def actor_update(dims, hyp, actor_blob, actor_blob_T, q_blob, q_blob_T, state, action, stats, m, v, t, lr, loss_out, ws,
