@@ -90,7 +90,7 @@ __device__ __forceinline__ void wide_layer_swish_d(float* Xs, const float* __res
   auto body = [&](auto guarded) {
     wide_foreach<MT>(acc, [&](int row, int col, float v) {
       const float z = v + ((col & 32) ? bias1 : bias0);
-      const float sig = 1.f / (1.f + __expf(-z));
+      const float sig = fast_rcp(1.f + __expf(-z));
       const float y = z * sig;
       Xs[row * LDX + col] = y;
       extra(guarded, row, col, y, sig * (1.f + z * (1.f - sig)));

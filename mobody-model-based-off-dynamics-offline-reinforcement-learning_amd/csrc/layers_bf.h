@@ -126,7 +126,7 @@ __device__ __forceinline__ int wide_layer_to_planes(float* Xs, char* Ps, float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float z = acc[mt][nt][r] + (nt ? bias1 : bias0);
-          const float sig = 1.f / (1.f + __expf(-z));
+          const float sig = fast_rcp(1.f + __expf(-z));
           const float y = z * sig;
           acc[mt][nt][r] = y;
           dv[mt][nt][r] = sig * (1.f + z * (1.f - sig));
@@ -193,7 +193,7 @@ __device__ __forceinline__ void bf_layer(float* Xs, const char* Ps, int e_in, co
         for (int r = 0; r < 16; ++r) {
           const float bias = nt ? bias1 : bias0;
           const float z = Split<PM>::F16 ? fmaf(acc[mt][nt][r], inv, bias) : acc[mt][nt][r] + bias;
-          const float sig = 1.f / (1.f + __expf(-z));
+          const float sig = fast_rcp(1.f + __expf(-z));
           acc[mt][nt][r] = z * sig;
           dv[mt][nt][r] = sig * (1.f + z * (1.f - sig));
         }

@@ -52,10 +52,24 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_SWISH = 2 };
 
+// 1 / x as ONE v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale x 2, v_rcp, four fma, v_div_fmas, v_div_fixup):
+// a Swish is exp + reciprocal + two multiplies, and the ensemble step evaluates ~500 of them per wave and 64-row tile in a kernel
+// whose vector ALU is as busy as its matrix pipe.  The results move by ~1e-7 relative, two orders inside the parity tolerance.
+#ifndef SWISH_FAST_RCP
+#define SWISH_FAST_RCP 1
+#endif
+__device__ __forceinline__ float fast_rcp(float x) {
+#if SWISH_FAST_RCP
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.f / x;
+#endif
+}
+
 template <int ACT>
 __device__ __forceinline__ float activate(float x) {
   if (ACT == ACT_RELU) return fmaxf(x, 0.f);
-  if (ACT == ACT_SWISH) return x / (1.f + __expf(-x));   // x*sigmoid(x), mobody_module.py:13-15
+  if (ACT == ACT_SWISH) return x * fast_rcp(1.f + __expf(-x));   // x*sigmoid(x), mobody_module.py:13-15
   return x;
 }
 
